@@ -1,0 +1,80 @@
+// pin_libstdcxx.cpp -- golden-vector generator (test infrastructure).
+//
+// The reference draws table indices with std::mt19937 +
+// std::uniform_int_distribution<int> (src/simulations.cpp:245-250).  Those live
+// in libstdc++, not in the reference tree.  This program runs the SYSTEM
+// libstdc++ (GCC 11.4 here) on fixed seeds and prints JSON that
+// tests/golden/make_golden.py stores under tests/golden/; the C oracle's
+// hand-written mt19937 + Lemire map must reproduce it exactly.
+//
+// It is NOT the reference: the per-path loop below is a second, independent
+// restatement (with the real library distributions) of src/simulations.cpp:
+// 240-252 with an explicit seed where the reference uses std::random_device.
+//
+// usage: pin_libstdcxx <table.txt>   (one float per line, percent units)
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <vector>
+
+static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+int main(int argc, char **argv) {
+  if (argc != 2) { std::fprintf(stderr, "usage: %s table.txt\n", argv[0]); return 2; }
+  std::vector<float> table;
+  { std::ifstream in(argv[1]); float v; while (in >> v) table.push_back(v); }
+  const uint32_t seeds[] = {0u, 1u, 1000u, 1001u, 5489u, 123456789u, 0x7fffffffu, 0xffffffffu};
+  const int ranges[] = {1127, 1, 2, 3, 1000, 65536, 1000003, 2147483647};
+
+  std::printf("{\n \"libstdcxx\": \"%d\",\n \"table_len\": %zu,\n", __GLIBCXX__, table.size());
+  // raw engine outputs
+  std::printf(" \"mt19937_raw\": [\n");
+  for (size_t s = 0; s < 8; s++) {
+    std::mt19937 rng(seeds[s]);
+    std::printf("  {\"seed\": %u, \"out\": [", seeds[s]);
+    for (int i = 0; i < 8; i++) std::printf("%s%lu", i ? "," : "", (unsigned long)rng());
+    std::printf("]}%s\n", s + 1 < 8 ? "," : "");
+  }
+  std::printf(" ],\n \"mt19937_default_10000th\": ");
+  { std::mt19937 rng; unsigned long v = 0; for (int i = 0; i < 10000; i++) v = rng(); std::printf("%lu,\n", v); }
+  // distribution outputs
+  std::printf(" \"uniform_int\": [\n");
+  bool first = true;
+  for (size_t s = 0; s < 8; s++)
+    for (size_t r = 0; r < 8; r++) {
+      std::mt19937 rng(seeds[s]);
+      std::uniform_int_distribution<int> uni(0, ranges[r] - 1);
+      std::printf("%s  {\"seed\": %u, \"range\": %d, \"out\": [", first ? "" : ",\n", seeds[s], ranges[r]);
+      first = false;
+      for (int i = 0; i < 48; i++) std::printf("%s%d", i ? "," : "", uni(rng));
+      std::printf("]}");
+    }
+  std::printf("\n ],\n");
+  // whole paths: explicit seed, table draw, fund * (100 + r) / 100 in binary32
+  std::printf(" \"paths\": [\n");
+  const unsigned periods[] = {1, 4, 360, 1000};
+  first = true;
+  for (unsigned P : periods)
+    for (uint32_t seed0 : {1000u, 4000000000u}) {
+      std::printf("%s  {\"n_periods\": %u, \"seed0\": %u, \"initial_capital\": 1000.0, \"final_bits\": [",
+                  first ? "" : ",\n", P, seed0);
+      first = false;
+      for (uint32_t id = 0; id < 32; id++) {
+        std::mt19937 rng(uint32_t(seed0 + id));
+        std::uniform_int_distribution<int> uni(0, int(table.size()) - 1);
+        float total = 1000.0f;
+        for (unsigned i = 0; i < P; i++) {
+          float r = table[uni(rng)];
+          float a = 100.0f + r;
+          float m = total * a;
+          total = m / 100.0f;
+        }
+        std::printf("%s%u", id ? "," : "", bits(total));
+      }
+      std::printf("]}");
+    }
+  std::printf("\n ]\n}\n");
+  return 0;
+}

@@ -1,0 +1,470 @@
+/*
+ * smmc_oracle.c -- CPU restatement of the Monte-Carlo returns engine.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the package
+ * stock_market_monte_carlo_amd/, include/, the CLIs) may include, link, import
+ * or execute this file.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker / the timed CPU
+ * baseline.
+ *
+ * PINNING STATUS: "parity unpinned" against an executed reference.
+ *   The reference ships no tests, golden vectors or fixtures for this path, and
+ *   its translation unit src/simulations.cpp cannot be compiled in this image
+ *   without writing stand-ins for third-party headers it includes ("csv.h" from
+ *   fast-cpp-csv-parser is absent), so no reference binary was built or run.
+ *   What IS pinned:
+ *     - mt19937 + uniform_int_distribution<int> (the libstdc++ code the reference
+ *       calls at src/simulations.cpp:245-247) against the system libstdc++ 11.4
+ *       through oracle/pin/pin_libstdcxx.cpp -> tests/golden/libstdcxx_*.json,
+ *       and the ISO C++ known answer (10000th output of mt19937() == 4123659995);
+ *     - Philox4x32-10 against the published Random123 known-answer vectors.
+ *   The compounding arithmetic itself is three IEEE-754 binary32 operations
+ *   restated from src/simulations.cpp:14-16.
+ *
+ * Two engines live here:
+ *   (R) "reference-faithful": per-path mt19937, Lemire index map, update_fund --
+ *       follows src/simulations.cpp:204-266 with deterministic per-path seeds
+ *       (the reference seeds from std::random_device and has no seed argument).
+ *       This is what bench.py times as the CPU baseline ("port").
+ *   (C) "counter stream v1": Philox4x32-10 keyed by the 64-bit seed, counter =
+ *       (global path id, step block, stream tag); table-indexed or Box-Muller
+ *       Gaussian draws; the same three-rounding compounding step.  The HIP
+ *       kernels must reproduce this engine bit-for-bit (final values, histogram
+ *       bucket counts, below-threshold counts).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ * -ffp-contract=off matters: every fused multiply-add below is an explicit
+ * fmaf(); nothing else may be contracted.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* Compounding core: src/simulations.cpp:14-22                                */
+/* ------------------------------------------------------------------------- */
+
+/* src/simulations.cpp:14-16 -- fund * (100.0f + r) / 100, r in percent.
+ * Three binary32 roundings: add, multiply, true divide (int 100 -> 100.0f). */
+ORC_API float orc_update_fund(float fund_value, float period_return) {
+  float a = 100.0f + period_return;
+  float m = fund_value * a;
+  return m / 100.0f;
+}
+
+/* src/simulations.cpp:18-22 -- totals[0] is the caller's start value;
+ * totals has n_periods + 1 entries. */
+ORC_API void orc_many_updates(const float *returns, float *totals, uint32_t n_periods) {
+  for (uint32_t i = 0; i < n_periods; i++)
+    totals[i + 1] = orc_update_fund(totals[i], returns[i]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* mt19937 (ISO C++ [rand.eng.mers], the engine at src/simulations.cpp:246)   */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+  uint32_t mt[624];
+  int idx;
+} orc_mt19937;
+
+static void mt_seed(orc_mt19937 *g, uint32_t seed) {
+  g->mt[0] = seed;
+  for (int i = 1; i < 624; i++)
+    g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->idx = 624;
+}
+
+static void mt_twist(orc_mt19937 *g) {
+  uint32_t *mt = g->mt;
+  for (int k = 0; k < 624; k++) {
+    uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+    uint32_t v = mt[(k + 397) % 624] ^ (y >> 1);
+    if (y & 1u) v ^= 0x9908b0dfu;
+    mt[k] = v;
+  }
+  g->idx = 0;
+}
+
+static inline uint32_t mt_next(orc_mt19937 *g) {
+  if (g->idx >= 624) mt_twist(g);
+  uint32_t y = g->mt[g->idx++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+/* libstdc++ 11 uniform_int_distribution<int>(0, range-1)(mt19937):
+ * /usr/include/c++/11/bits/uniform_int_dist.h:241-268 (_S_nd, Lemire's nearly
+ * divisionless method with 64-bit product) selected at :294-323 because
+ * mt19937's range is exactly 2^32-1.  Call site: src/simulations.cpp:247,250. */
+static inline uint32_t lemire_index(orc_mt19937 *g, uint32_t range) {
+  uint64_t product = (uint64_t)mt_next(g) * (uint64_t)range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    uint32_t threshold = (uint32_t)(-range) % range;
+    while (low < threshold) {
+      product = (uint64_t)mt_next(g) * (uint64_t)range;
+      low = (uint32_t)product;
+    }
+  }
+  return (uint32_t)(product >> 32);
+}
+
+/* n raw outputs of mt19937(seed) -- for the ISO known-answer test. */
+ORC_API void orc_mt19937_raw(uint32_t seed, uint32_t n, uint32_t *out) {
+  orc_mt19937 g;
+  mt_seed(&g, seed);
+  for (uint32_t i = 0; i < n; i++) out[i] = mt_next(&g);
+}
+
+/* n draws of uniform_int_distribution<int>(0, range-1) on mt19937(seed). */
+ORC_API void orc_mt19937_indices(uint32_t seed, uint32_t range, uint32_t n, uint32_t *out) {
+  orc_mt19937 g;
+  mt_seed(&g, seed);
+  for (uint32_t i = 0; i < n; i++) out[i] = lemire_index(&g, range);
+}
+
+/* (R) one path of src/simulations.cpp:240-252 with an explicit seed. */
+static float ref_one_path(uint32_t seed, uint32_t n_periods, float initial_capital,
+                          const float *table, uint32_t table_len) {
+  orc_mt19937 g;
+  mt_seed(&g, seed);
+  float total = initial_capital;
+  for (uint32_t i = 0; i < n_periods; i++)
+    total = orc_update_fund(total, table[lemire_index(&g, table_len)]);
+  return total;
+}
+
+/* (R) src/simulations.cpp:204-266: OpenMP schedule(dynamic) over blocks of 1000
+ * paths.  Path `id` is seeded with (uint32_t)(seed0 + id) where the reference
+ * uses a fresh std::random_device per path.  n_threads <= 0 means the
+ * reference's max(1, hardware_concurrency - 1) (:218-219).  Returns the number
+ * of threads used.  final_values must hold n_paths floats (:252). */
+ORC_API int orc_ref_mc_simulations(int64_t n_paths, uint32_t n_periods, float initial_capital,
+                                   const float *table, uint32_t table_len, uint32_t seed0,
+                                   float *final_values, int n_threads) {
+  const int64_t block_size = 1000;
+  const int64_t n_blocks = (n_paths + block_size - 1) / block_size;
+  int used = 1;
+#ifdef _OPENMP
+  if (n_threads <= 0) {
+    n_threads = omp_get_num_procs() - 1;
+    if (n_threads < 1) n_threads = 1;
+  }
+  used = n_threads;
+#pragma omp parallel for schedule(dynamic) num_threads(n_threads)
+#endif
+  for (int64_t b = 0; b < n_blocks; b++) {
+    int64_t first = b * block_size;
+    int64_t last = first + block_size < n_paths ? first + block_size : n_paths;
+    for (int64_t id = first; id < last; id++)
+      final_values[id] =
+          ref_one_path((uint32_t)(seed0 + (uint64_t)id), n_periods, initial_capital, table, table_len);
+  }
+  return used;
+}
+
+/* ------------------------------------------------------------------------- */
+/* (C) counter stream v1                                                      */
+/* ------------------------------------------------------------------------- */
+
+/* Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy
+ * as 1, 2, 3", SC'11; Random123 philox.h).  Published algorithm restated. */
+ORC_API void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+#define ORC_MODE_TABLE 0
+#define ORC_MODE_GAUSSIAN 1
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* ln(x) for normal positive binary32 x, Cephes-style degree-8 kernel on
+ * [sqrt(1/2), sqrt(2)); every operation is a single rounded binary32 op. */
+ORC_API float orc_log_kernel(float x) {
+  uint32_t ix = f2u(x);
+  ix += 0x3f800000u - 0x3f3504f3u;
+  int32_t e = (int32_t)(ix >> 23) - 127;
+  ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+  float f = u2f(ix) - 1.0f;
+  float fe = (float)e;
+  float z = f * f;
+  float p = 7.0376836292E-2f;
+  p = fmaf(p, f, -1.1514610310E-1f);
+  p = fmaf(p, f, 1.1676998740E-1f);
+  p = fmaf(p, f, -1.2420140846E-1f);
+  p = fmaf(p, f, 1.4249322787E-1f);
+  p = fmaf(p, f, -1.6668057665E-1f);
+  p = fmaf(p, f, 2.0000714765E-1f);
+  p = fmaf(p, f, -2.4999993993E-1f);
+  p = fmaf(p, f, 3.3333331174E-1f);
+  float fz = f * z;
+  float y = fz * p;
+  y = fmaf(fe, -2.12194440e-4f, y);
+  y = fmaf(-0.5f, z, y);
+  float r = f + y;
+  r = fmaf(fe, 0.693359375f, r);
+  return r;
+}
+
+/* Box-Muller on two 32-bit words: ua -> radius, ub -> angle.
+ *   U1    = fma((float)ua, 2^-32, 2^-33)          in (0, 1]
+ *   r     = sqrtf(-2 * log_kernel(U1))            (IEEE sqrt)
+ *   v     = ub + 2^29 (mod 2^32); q = v >> 30; g = (v & (2^30-1)) - 2^29
+ *   theta = 2*pi*ub/2^32 = q*pi/2 + alpha, alpha = (float)g * fl(pi * 2^-31)
+ *   sin/cos(alpha) from degree-7/8 kernels on [-pi/4, pi/4), then the quadrant
+ *   rotation by sign-bit XOR and a swap.
+ *   z_cos = r * cos(theta), z_sin = r * sin(theta). */
+ORC_API void orc_box_muller(uint32_t ua, uint32_t ub, float *z_cos, float *z_sin) {
+  float u1 = fmaf((float)ua, 0x1p-32f, 0x1p-33f);
+  float l = orc_log_kernel(u1);
+  float t = -2.0f * l;
+  float r = sqrtf(t);
+
+  uint32_t v = ub + 0x20000000u;
+  int32_t g = (int32_t)(v & 0x3fffffffu) - 0x20000000;
+  float a = (float)g * 0x1.921fb6p-30f;
+  float z = a * a;
+  float ps = fmaf(-1.9515295891E-4f, z, 8.3321608736E-3f);
+  ps = fmaf(ps, z, -1.6666654611E-1f);
+  float az = a * z;
+  float s = fmaf(az, ps, a);
+  float pc = fmaf(2.443315711809948E-5f, z, -1.388731625493765E-3f);
+  pc = fmaf(pc, z, 4.166664568298827E-2f);
+  float zz = z * z;
+  float h = fmaf(-0.5f, z, 1.0f);
+  float c = fmaf(zz, pc, h);
+
+  uint32_t swap = v & 0x40000000u;
+  uint32_t sign_s = v & 0x80000000u;
+  uint32_t sign_c = (v + 0x40000000u) & 0x80000000u;
+  float cb = swap ? s : c;
+  float sb = swap ? c : s;
+  float ct = u2f(f2u(cb) ^ sign_c);
+  float st = u2f(f2u(sb) ^ sign_s);
+  *z_cos = r * ct;
+  *z_sin = r * st;
+}
+
+typedef struct {
+  int32_t mode;          /* ORC_MODE_* */
+  uint32_t n_periods;
+  uint64_t seed;         /* Philox key = (lo32, hi32) */
+  uint64_t first_path;   /* global id of path 0 of this call */
+  uint64_t n_paths;
+  float initial_capital;
+  float gauss_mean;      /* percent per period */
+  float gauss_std;       /* percent per period */
+  const float *table;    /* percent per period, table_len entries */
+  uint32_t table_len;
+  uint32_t n_bins;       /* 0 = no histogram */
+  float hist_lo, hist_hi;
+  float below_threshold;
+} orc_params;
+
+typedef struct {
+  uint64_t count;
+  uint64_t below;        /* v < below_threshold */
+  uint64_t underflow;    /* v < hist_lo */
+  uint64_t overflow;     /* !(v < hist_hi), NaN included */
+  double sum;
+  double sumsq;
+  float min, max;
+} orc_stats;
+
+/* The draws of one path, period by period, in percent (table mode: the table
+ * entry; Gaussian mode: fma(std, z, mean)).  Exposed so tests can check the
+ * draw stream itself. */
+static void path_returns_block(const orc_params *p, uint64_t path, uint32_t blk, float out[4],
+                               uint32_t idx_out[4]) {
+  uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), blk, (uint32_t)p->mode};
+  uint32_t key[2] = {(uint32_t)p->seed, (uint32_t)(p->seed >> 32)};
+  uint32_t u[4];
+  orc_philox4x32_10(ctr, key, u);
+  if (p->mode == ORC_MODE_TABLE) {
+    for (int j = 0; j < 4; j++) {
+      uint32_t idx = (uint32_t)(((uint64_t)u[j] * p->table_len) >> 32);
+      if (idx_out) idx_out[j] = idx;
+      out[j] = p->table[idx];
+    }
+  } else {
+    float z[4];
+    orc_box_muller(u[0], u[1], &z[0], &z[1]);
+    orc_box_muller(u[2], u[3], &z[2], &z[3]);
+    for (int j = 0; j < 4; j++) out[j] = fmaf(p->gauss_std, z[j], p->gauss_mean);
+  }
+}
+
+/* Writes the n_periods returns of global path `path` (percent). */
+ORC_API void orc_counter_path_returns(const orc_params *p, uint64_t path, float *returns) {
+  for (uint32_t i = 0; i < p->n_periods; i += 4) {
+    float r[4];
+    path_returns_block(p, path, i / 4, r, 0);
+    for (uint32_t j = 0; j < 4 && i + j < p->n_periods; j++) returns[i + j] = r[j];
+  }
+}
+
+static float counter_one_path(const orc_params *p, uint64_t path, float *trajectory) {
+  float total = p->initial_capital;
+  if (trajectory) trajectory[0] = total;
+  for (uint32_t i = 0; i < p->n_periods; i += 4) {
+    float r[4];
+    path_returns_block(p, path, i / 4, r, 0);
+    for (uint32_t j = 0; j < 4 && i + j < p->n_periods; j++) {
+      total = orc_update_fund(total, r[j]);
+      if (trajectory) trajectory[i + j + 1] = total;
+    }
+  }
+  return total;
+}
+
+/* Histogram bucket contract (build-defined; the reference bins only inside a
+ * third-party plotting call): inv = (double)n_bins / ((double)hi - (double)lo);
+ * v < lo -> underflow; v < hi -> bucket min((int)(((double)v - lo) * inv),
+ * n_bins - 1); anything else (v >= hi or NaN) -> overflow. */
+ORC_API int32_t orc_hist_bucket(float v, float lo, float hi, uint32_t n_bins) {
+  double inv = (double)n_bins / ((double)hi - (double)lo);
+  if (v < lo) return -1;
+  if (v < hi) {
+    int32_t b = (int32_t)(((double)v - (double)lo) * inv);
+    return b < (int32_t)n_bins - 1 ? b : (int32_t)n_bins - 1;
+  }
+  return (int32_t)n_bins;
+}
+
+/* (C) engine.  Any of final_values (n_paths floats), hist (n_bins u64, zeroed
+ * here), stats, trajectories (n_paths x (n_periods+1) floats, path-major) may be
+ * NULL.  Parallelised over paths when OpenMP is on; sums are accumulated in
+ * global path order afterwards so the result does not depend on the thread
+ * count. */
+ORC_API int orc_counter_mc(const orc_params *p, float *final_values, uint64_t *hist, orc_stats *stats,
+                           float *trajectories, int n_threads) {
+  if (p->mode == ORC_MODE_TABLE && (p->table == 0 || p->table_len == 0)) return -1;
+  int64_t n = (int64_t)p->n_paths;
+  float *fv = final_values;
+  if (!fv) {
+    fv = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    if (!fv) return -2;
+  }
+#ifdef _OPENMP
+  if (n_threads <= 0) n_threads = omp_get_num_procs();
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+#endif
+  for (int64_t i = 0; i < n; i++) {
+    float *traj = trajectories ? trajectories + (size_t)i * (p->n_periods + 1) : 0;
+    fv[i] = counter_one_path(p, p->first_path + (uint64_t)i, traj);
+  }
+  if (hist) memset(hist, 0, sizeof(uint64_t) * p->n_bins);
+  orc_stats s;
+  memset(&s, 0, sizeof s);
+  s.min = INFINITY;
+  s.max = -INFINITY;
+  for (int64_t i = 0; i < n; i++) {
+    float v = fv[i];
+    s.count++;
+    if (v < p->below_threshold) s.below++;
+    s.sum += (double)v;
+    s.sumsq += (double)v * (double)v;
+    if (v < s.min) s.min = v;
+    if (v > s.max) s.max = v;
+    if (p->n_bins) {
+      int32_t b = orc_hist_bucket(v, p->hist_lo, p->hist_hi, p->n_bins);
+      if (b < 0) s.underflow++;
+      else if (b >= (int32_t)p->n_bins) s.overflow++;
+      else if (hist) hist[b]++;
+    }
+  }
+  if (stats) *stats = s;
+  if (!final_values) free(fv);
+  return 0;
+}
+
+/* Per-chunk (256 consecutive paths) mean and population variance -- the shape of
+ * the reference's reduceBlock output (src/simulations.cu:231-246, one pair per
+ * 256-thread block) but dividing by the true chunk length for a partial last
+ * chunk.  Double accumulation, rounded to float once. */
+ORC_API void orc_chunk_mean_var(const float *values, uint64_t n, uint32_t chunk, float *means,
+                                float *variances) {
+  uint64_t n_chunks = (n + chunk - 1) / chunk;
+  for (uint64_t c = 0; c < n_chunks; c++) {
+    uint64_t a = c * chunk, b = a + chunk < n ? a + chunk : n;
+    double s = 0;
+    for (uint64_t i = a; i < b; i++) s += (double)values[i];
+    double m = s / (double)(b - a);
+    double q = 0;
+    for (uint64_t i = a; i < b; i++) {
+      double d = (double)values[i] - m;
+      q += d * d;
+    }
+    means[c] = (float)m;
+    variances[c] = (float)(q / (double)(b - a));
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Checks used by tests for device-side shortcuts                             */
+/* ------------------------------------------------------------------------- */
+
+/* The HIP kernels divide by 100 with q = x*c; e = fma(-100, q, x); q' = fma(e, c, q)
+ * (c = fl(1/100)).  Counts the binary32 patterns in [bits_lo, bits_hi) for which
+ * that differs from the IEEE quotient x / 100.0f; first mismatch is stored. */
+ORC_API uint64_t orc_div100_mismatches(uint32_t bits_lo, uint32_t bits_hi, uint32_t *first_bad) {
+  const float c = 0.01f;
+  uint64_t bad = 0;
+  for (uint64_t b = bits_lo; b < bits_hi; b++) {
+    float x = u2f((uint32_t)b);
+    float q = x * c;
+    float e = fmaf(-100.0f, q, x);
+    float q2 = fmaf(e, c, q);
+    float ref = x / 100.0f;
+    if (f2u(q2) != f2u(ref)) {
+      if (!bad && first_bad) *first_bad = (uint32_t)b;
+      bad++;
+    }
+  }
+  return bad;
+}
+
+/* Scans binary32 patterns of U1 in [bits_lo, bits_hi): returns how many give a
+ * positive log_kernel (which would make the Box-Muller radius NaN) and the
+ * largest relative error against the double-precision log. */
+ORC_API uint64_t orc_log_kernel_scan(uint32_t bits_lo, uint32_t bits_hi, double *max_rel_err) {
+  uint64_t positive = 0;
+  double worst = 0;
+  for (uint64_t b = bits_lo; b < bits_hi; b++) {
+    float x = u2f((uint32_t)b);
+    float l = orc_log_kernel(x);
+    if (l > 0.0f) positive++;
+    double ref = log((double)x);
+    if (ref != 0.0) {
+      double rel = fabs(((double)l - ref) / ref);
+      if (rel > worst) worst = rel;
+    }
+  }
+  if (max_rel_err) *max_rel_err = worst;
+  return positive;
+}
