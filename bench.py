@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X Monte-Carlo returns engine.
+
+Metric (BASELINE.json): simulated paths/sec at 360 periods.  One "step" = one pass
+of the hot path over one batch of synthetic input: PATHS_PER_GPU paths x 360 periods
+per GPU, Gaussian returns (BASELINE configs[1]: "Gaussian returns, 360 periods x 1e8
+paths, 1 x MI355X, final-value only + block-reduce mean"), producing the final value
+of every path in HBM, the per-256-path block means/variances and the fused
+statistics record (sum, sum of squares, below-count, 100-bucket histogram).
+
+Multi-GPU (`torchrun`-style launch, one rank per GPU): paths shard by contiguous
+global id ranges (weak scaling: PATHS_PER_GPU each); the only exchange is one RCCL
+all_gather of the ~900-byte statistics record per step, merged in rank order.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline      HBM roofline of the dominant kernel (paths_kernel): algorithmic bytes
+                (4 B per path, the coalesced final-value store) / its HIP-event time.
+                The kernel is VALU-bound by design, so this fraction is tiny; the
+                `valu` object carries the roof that actually binds.
+  cpu_baseline  the reference's CPU algorithm (oracle engine R: mt19937 + Lemire +
+                update_fund, OpenMP hw-1 threads) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PERIODS = 360
+PATHS_PER_GPU = 100_000_000
+SEED = 0x5EED5EED5EED5EED
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock = 7.86e13 lane-ops/s
+# VALU lane-ops per path-period issued by paths_kernel (counted from the gfx950 ISA,
+# DESIGN.md section 5; quarter-rate integer multiplies counted as 4)
+VALU_SLOTS_PER_STEP = {"gaussian": 62.0, "table": 39.0}
+
+
+def load_table():
+    vals = []
+    with open(os.path.join(ROOT, "data", "SP500_monthly_returns.csv")) as f:
+        col = f.readline().strip().split(",").index("returns")
+        for line in f:
+            cell = line.rstrip("\n").split(",")[col]
+            if cell:
+                vals.append(np.float32(cell))
+    return np.array(vals, dtype=np.float32)
+
+
+def cpu_baseline(table, budget_s=15.0):
+    """Times the oracle's reference-faithful engine (R) -- the checker, used here only as
+    the CPU baseline the metric asks for."""
+    from oracle import oracle as O
+    O.build()
+    # the reference uses hardware_concurrency() - 1 threads (src/simulations.cpp:218-219);
+    # count the cores this process may actually run on, not the host's
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 2
+    threads = max(1, cores - 1)
+    n, dt, used = 50_000, 0.0, threads
+    while True:  # grow the sample until it is >= 2/3 of the budget of CPU wall time
+        t0 = time.perf_counter()
+        _, used = O.ref_mc_simulations(n, N_PERIODS, 1000.0, table, 12345, n_threads=threads)
+        dt = time.perf_counter() - t0
+        if dt >= budget_s * 2 / 3 or n >= 200_000_000:
+            break
+        n = int(n * min(max(budget_s / max(dt, 1e-3), 1.5), 20.0))
+        n -= n % 1000
+    return {"value": n / dt, "unit": "paths/s", "cores": used, "kind": "port",
+            "sample": f"{n} paths x {N_PERIODS} periods, table mode (T={table.size}), oracle engine R "
+                      f"(per-path mt19937 + Lemire + update_fund, OpenMP dynamic blocks of 1000), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["gaussian", "table"], default="gaussian")
+    ap.add_argument("--paths-per-gpu", type=int, default=PATHS_PER_GPU)
+    ap.add_argument("--periods", type=int, default=N_PERIODS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--outputs", choices=["all", "final", "stats"], default="all",
+                    help="all = final values + block means + statistics (configs[1]); final = final values only; "
+                         "stats = statistics only (no per-path HBM write)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import stock_market_monte_carlo_amd as S
+    from stock_market_monte_carlo_amd.engine import merge_stats_bytes, stats_from_bytes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    table = load_table()
+    eng = S.Engine(local_rank)
+    eng.set_table(table)
+    mode = S.MODE_GAUSSIAN if args.mode == "gaussian" else S.MODE_TABLE
+    n = args.paths_per_gpu
+    sim = S.Engine.make_sim(n, args.periods, mode, SEED, first_path=rank * n, initial_capital=1000.0,
+                            gauss_mean=0.5, gauss_std=0.83333, n_bins=100, hist_lo=0.0, hist_hi=20000.0)
+    want_final = args.outputs in ("all", "final")
+    want_chunks = args.outputs == "all"
+    want_stats = args.outputs in ("all", "stats")
+    final = torch.empty(n, dtype=torch.float32, device=eng.tdevice) if want_final else None
+    rec_bytes = 64 + 8 * 100
+    gathered = torch.empty(world * rec_bytes, dtype=torch.uint8, device=eng.tdevice) if world > 1 else None
+
+    def step():
+        r = eng.simulate(sim, want_final=want_final, want_chunk_stats=want_chunks, want_stats=want_stats, out=final)
+        if world > 1 and want_stats:
+            dist.all_gather_into_tensor(gathered, r.stats_raw)
+        return r
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = eng.kernel_ms()
+    eng.timing(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.tdevice)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    stats = None
+    if want_stats:
+        if world > 1:
+            raw = gathered.cpu().numpy().tobytes()
+            stats = stats_from_bytes(merge_stats_bytes([raw[i * rec_bytes:(i + 1) * rec_bytes] for i in range(world)]))
+        else:
+            stats = eng.read_stats(last.stats_raw)
+        assert stats.count == n * world, (stats.count, n * world)
+
+    if rank == 0:
+        total_paths = n * world * args.steps
+        value = total_paths / dt
+        k_avg_s = kernel_ms / 1e3 / max(launches, 1)
+        bytes_per_launch = 4.0 * n if want_final else 0.0
+        achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        slots = VALU_SLOTS_PER_STEP[args.mode]
+        valu_ach = n * args.periods * slots / k_avg_s if k_avg_s > 0 else 0.0
+        out = {
+            "metric": "simulated paths/sec at N=360 periods" if args.periods == 360
+                      else f"simulated paths/sec at N={args.periods} periods",
+            "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.mode} returns, {args.periods} periods x {n:.0e} paths per GPU, "
+                                   f"outputs={args.outputs} (BASELINE configs[1])",
+                       "paths_per_gpu": n, "n_periods": args.periods, "mode": args.mode, "seed": hex(SEED),
+                       "parallelism": f"path-range shards x{world}, one RCCL all_gather of the stats record per step"
+                                      if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "paths_kernel", "kernel_ms": k_avg_s * 1e3, "bytes_per_launch": bytes_per_launch,
+                         "note": "VALU-bound kernel: 4 B of HBM traffic per 360-period path by construction; "
+                                 "see valu"},
+            "valu": {"bound": "valu-issue", "achieved": valu_ach, "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s",
+                     "frac": valu_ach / VALU_PEAK_LANEOPS, "slots_per_path_period": slots},
+        }
+        if stats is not None:
+            out["result"] = {"mean": stats.mean, "std": stats.std, "below_initial": stats.below,
+                             "hist_total": int(stats.hist.sum()) + stats.underflow + stats.overflow}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(table)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

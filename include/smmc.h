@@ -1,0 +1,182 @@
+/*
+ * smmc.h -- C ABI of the MI355X Monte-Carlo returns engine (libsmmc_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of matthijsvk/stock_market_monte_carlo:
+ * the Monte-Carlo returns engine of src/simulations.cpp / src/simulations.cu.
+ * Plain pointers and sizes only; no C++ or torch types.  Each entry point names
+ * the reference interface it stands in for (paths relative to the reference
+ * tree).  The C++ header include/stock_market_monte_carlo/simulations.h re-exports
+ * the reference's own free-function signatures on top of these.
+ *
+ * Threading: an engine is bound to one device and one stream and is not
+ * re-entrant; use one engine per host thread (engines are cheap).  Different
+ * engines may be used concurrently.  No call exits the process: every failure
+ * is a negative return code plus smmc_last_error() (thread-local text).
+ *
+ * Random stream ("counter stream v1"): Philox4x32-10, key =
+ * the 64-bit seed, counter = (global path id, period/4, mode).  A path's value
+ * depends only on (seed, global path id, parameters), never on the launch
+ * geometry, the shard it falls in or the number of GPUs.
+ */
+#ifndef SMMC_H
+#define SMMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMMC_ABI_VERSION 1
+
+/* return codes */
+#define SMMC_OK 0
+#define SMMC_ERR_INVALID (-1)   /* bad argument */
+#define SMMC_ERR_HIP (-2)       /* a HIP runtime call failed */
+#define SMMC_ERR_NO_DEVICE (-3) /* no usable gfx950 device */
+#define SMMC_ERR_NOMEM (-4)
+
+/* how a period's return is drawn */
+#define SMMC_MODE_TABLE 0    /* i.i.d. with replacement from the returns table   */
+#define SMMC_MODE_GAUSSIAN 1 /* N(gauss_mean, gauss_std), Box-Muller             */
+
+/* smmc_sim.flags */
+#define SMMC_FLAG_EXACT_DIV 1u /* force the IEEE divide kernel variant */
+
+/* paths per chunk of the per-chunk mean/variance outputs: the reference's
+ * THREADS_PER_BLOCK (src/simulations.cu:17), one (mean, variance) pair per block
+ * in mc_simulations_gpu_kernel_reduceBlock (src/simulations.cu:240-246). */
+#define SMMC_CHUNK 256
+
+/* largest returns table an engine accepts (it is staged whole in LDS) */
+#define SMMC_MAX_TABLE 16384
+/* largest histogram */
+#define SMMC_MAX_BINS 4096
+
+typedef struct smmc_engine smmc_engine;
+
+/* One simulation request: n_paths independent paths with global ids
+ * first_path .. first_path + n_paths - 1, n_periods compounding steps each.
+ * Mirrors the argument lists of mc_simulations (src/simulations.cpp:204-209) and
+ * mc_simulations_gpu (src/simulations.cu:661-667) plus what the reference leaves
+ * implicit (seed, draw mode) or computes on the host afterwards (statistics:
+ * examples/benchmark_mc_gpu.cpp:7-41). */
+typedef struct smmc_sim {
+  uint32_t struct_size;   /* = sizeof(smmc_sim) */
+  int32_t mode;           /* SMMC_MODE_*                                        */
+  uint64_t seed;          /* Philox key                                         */
+  uint64_t first_path;    /* global id of the first path (sharding offset)      */
+  uint64_t n_paths;       /* max_n_simulations                                  */
+  uint32_t n_periods;     /* n_periods                                          */
+  float initial_capital;  /* initial_capital                                    */
+  float gauss_mean;       /* percent per period (examples/monte_carlo_simulated.cpp:11) */
+  float gauss_std;        /* percent per period (examples/monte_carlo_simulated.cpp:12) */
+  uint32_t n_bins;        /* histogram buckets, 0 = none, <= SMMC_MAX_BINS      */
+  float hist_lo, hist_hi; /* bucket range [lo, hi)                              */
+  float below_threshold;  /* count of final values < this                       */
+  uint32_t flags;         /* SMMC_FLAG_*                                        */
+} smmc_sim;
+
+/* Packed statistics record as the device writes it: this header followed by
+ * n_bins uint64 bucket counts.  smmc_stats_bytes(n_bins) is its size.  All
+ * integer fields are exact; sum/sumsq are double-precision sums of the float
+ * final values in a fixed (launch-geometry dependent) order. */
+typedef struct smmc_stats {
+  uint64_t count;     /* paths simulated                                       */
+  uint64_t below;     /* final value < below_threshold (benchmark_mc_gpu.cpp:30-41) */
+  uint64_t underflow; /* final value < hist_lo                                 */
+  uint64_t overflow;  /* final value >= hist_hi, or NaN                        */
+  double sum;         /* sum of final values (benchmark_mc_gpu.cpp:13-17)      */
+  double sumsq;       /* sum of squares                                        */
+  float min, max;     /* +inf / -inf when count == 0                           */
+  uint32_t n_bins;
+  uint32_t reserved;
+} smmc_stats;
+
+/* ---- host scalar functions ------------------------------------------------ */
+
+/* update_fund, src/simulations.cpp:14-16: fund * (100.0f + r) / 100 in binary32. */
+float smmc_update_fund(float fund_value, float period_return);
+
+/* __many_updates, src/simulations.cpp:18-22: totals[0] is read, totals[1..n] written. */
+void smmc_many_updates(const float *returns, float *totals, uint32_t n_periods);
+
+/* ---- library / device ------------------------------------------------------ */
+
+int smmc_abi_version(void);
+const char *smmc_last_error(void);
+
+/* Number of visible HIP devices (0 and SMMC_OK when there is none). */
+int smmc_device_count(int *count);
+
+/* ---- engine ---------------------------------------------------------------- */
+
+/* Pass as `stream` to make the engine create (and own) a non-blocking stream. */
+#define SMMC_STREAM_NEW ((void *)(intptr_t)-1)
+
+/* Binds an engine to `device`.  `stream` is the hipStream_t to launch on (e.g. the
+ * caller's current torch stream); NULL is the device's default stream, as in every
+ * HIP call; SMMC_STREAM_NEW asks for an engine-owned non-blocking stream.
+ * Replaces the per-call cudaSetDevice/cudaMalloc/cudaFree plan of
+ * create_plan_v2 (src/simulations.cu:568-574, 599-607, 632-637). */
+int smmc_engine_create(int device, void *stream, smmc_engine **out);
+void smmc_engine_destroy(smmc_engine *e);
+
+/* Uploads the historical-returns table (percent units, host memory).  Replaces
+ * the H2D table copies at src/simulations.cu:382,451,525,617.  Asynchronous on
+ * the engine stream; the host array may be reused on return. */
+int smmc_engine_set_table(smmc_engine *e, const float *returns_percent, uint32_t n);
+
+/* Enqueues one simulation on the engine stream and returns without waiting.
+ * All output pointers are DEVICE pointers on the engine's device; any may be NULL:
+ *   d_final       n_paths floats, final value of each path, coalesced
+ *                 (totals of mc_simulations_gpu_kernel, src/simulations.cu:151)
+ *   d_chunk_mean  ceil(n_paths / SMMC_CHUNK) floats, mean of each 256-path chunk
+ *   d_chunk_var   same length, population variance of each chunk
+ *                 (means/variances of the reduceBlock kernel, src/simulations.cu:240-246)
+ *   d_stats       smmc_stats_bytes(sim->n_bins) bytes, packed statistics record
+ * Replaces mc_simulations_gpu_launcher / _reduceBlock_launcher
+ * (src/simulations.cu:345-473). */
+int smmc_engine_simulate(smmc_engine *e, const smmc_sim *sim, float *d_final, float *d_chunk_mean,
+                         float *d_chunk_var, void *d_stats);
+
+/* Same, but keeps every trajectory: d_traj is n_paths x (n_periods + 1) floats,
+ * path-major (row i = the `values` vector of path i, values[0] = initial capital)
+ * -- mc_data of mc_simulations_keepdata (src/simulations.cpp:139-186).  d_final
+ * may be NULL. */
+int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_traj, float *d_final);
+
+/* Blocks until everything enqueued on the engine stream has finished. */
+int smmc_engine_sync(smmc_engine *e);
+
+/* Simulates into HOST memory: final values of all paths are produced in chunks
+ * and copied back on a side stream while the next chunk computes (the async
+ * cudaMemcpy pattern of mc_simulations_multi_gpu_launcher_async,
+ * src/simulations.cu:615-626, without its extra host copy :643-644).
+ * host_final: n_paths floats (pinned or pageable).  progress, if not NULL, is set
+ * to the number of finished paths after every chunk (the n_simulations counter
+ * of src/simulations.cpp:254).  stats/hist (host) may be NULL.  Synchronous. */
+int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *host_final,
+                                 volatile int64_t *progress, smmc_stats *stats, uint64_t *hist);
+
+/* Device-time instrumentation: when enabled, every simulate call brackets its
+ * main kernel with HIP events on the engine stream.  smmc_engine_kernel_ms
+ * synchronises, returns the number of timed launches and their summed duration
+ * in milliseconds, and clears the log. */
+int smmc_engine_timing(smmc_engine *e, int enable);
+int smmc_engine_kernel_ms(smmc_engine *e, double *total_ms, uint32_t *launches);
+
+/* Launch geometry the engine will use (workgroups x threads), for reports. */
+int smmc_engine_geometry(smmc_engine *e, uint32_t *grid, uint32_t *block, uint32_t *compute_units);
+
+/* ---- statistics record helpers (host) --------------------------------------- */
+
+uint64_t smmc_stats_bytes(uint32_t n_bins);
+/* dst += src for two packed records with equal n_bins (host memory).  Merging
+ * shards in ascending rank order gives a result independent of timing. */
+int smmc_stats_merge(void *dst_packed, const void *src_packed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMMC_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI in include/smmc.h (libsmmc_hip.so).
+
+There is no fallback: if the HIP library is missing or fails to load, importing the
+engine raises.  Nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libsmmc_hip.so")
+
+ABI_VERSION = 1
+MODE_TABLE = 0
+MODE_GAUSSIAN = 1
+FLAG_EXACT_DIV = 1
+CHUNK = 256
+MAX_TABLE = 16384
+MAX_BINS = 4096
+
+
+class Sim(C.Structure):
+    """smmc_sim"""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("mode", C.c_int32),
+        ("seed", C.c_uint64),
+        ("first_path", C.c_uint64),
+        ("n_paths", C.c_uint64),
+        ("n_periods", C.c_uint32),
+        ("initial_capital", C.c_float),
+        ("gauss_mean", C.c_float),
+        ("gauss_std", C.c_float),
+        ("n_bins", C.c_uint32),
+        ("hist_lo", C.c_float),
+        ("hist_hi", C.c_float),
+        ("below_threshold", C.c_float),
+        ("flags", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    """smmc_stats (header of the packed record; n_bins uint64 counts follow)"""
+    _fields_ = [
+        ("count", C.c_uint64),
+        ("below", C.c_uint64),
+        ("underflow", C.c_uint64),
+        ("overflow", C.c_uint64),
+        ("sum", C.c_double),
+        ("sumsq", C.c_double),
+        ("min", C.c_float),
+        ("max", C.c_float),
+        ("n_bins", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+# every symbol include/smmc.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("smmc_update_fund", C.c_float, [C.c_float, C.c_float]),
+    ("smmc_many_updates", None, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    ("smmc_abi_version", C.c_int, []),
+    ("smmc_last_error", C.c_char_p, []),
+    ("smmc_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("smmc_engine_create", C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("smmc_engine_destroy", None, [C.c_void_p]),
+    ("smmc_engine_set_table", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    ("smmc_engine_simulate", C.c_int,
+     [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("smmc_engine_simulate_keepdata", C.c_int, [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p]),
+    ("smmc_engine_sync", C.c_int, [C.c_void_p]),
+    ("smmc_engine_simulate_to_host", C.c_int,
+     [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    ("smmc_engine_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("smmc_engine_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    ("smmc_engine_geometry", C.c_int,
+     [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("smmc_stats_bytes", C.c_uint64, [C.c_uint32]),
+    ("smmc_stats_merge", C.c_int, [C.c_void_p, C.c_void_p]),
+]
+
+_lib = None
+
+
+class SmmcError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libsmmc_hip.so once.  Raises if it is missing: there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SmmcError(
+                f"{LIB_PATH} is missing: build it with `python -m stock_market_monte_carlo_amd.build` "
+                "(hipcc, gfx950).  This package has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm wheels carry their own libamdhip64
+        # (soname libamdhip64.so.7, the one our library asks for).  Loading torch first
+        # makes the dynamic linker hand that copy to libsmmc_hip.so, so streams and
+        # device pointers can cross between the two; the other order would map a
+        # second runtime (/opt/rocm) that cannot see the device.
+        import torch  # noqa: F401
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.smmc_abi_version() != ABI_VERSION:
+            raise SmmcError(f"libsmmc_hip.so has ABI {L.smmc_abi_version()}, binding expects {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SmmcError(f"smmc error {rc}: {lib().smmc_last_error().decode(errors='replace')}")

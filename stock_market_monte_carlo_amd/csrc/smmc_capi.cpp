@@ -1,0 +1,508 @@
+// smmc_capi.cpp -- the C ABI declared in include/smmc.h: engine lifetime, argument
+// checking, kernel-variant selection, streams/events, the host-buffer pipeline.
+//
+// Host runtime counterpart of the reference launchers (src/simulations.cu:345-697),
+// re-designed: a long-lived engine per device instead of cudaMalloc/cudaFree per
+// call, every HIP call checked and reported through a return code (the reference
+// prints and exit()s, src/simulations.cu:23-30), no device-wide synchronisation.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+#include "smmc_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define SMMC_HIP(call)                                                                         \
+  do {                                                                                         \
+    hipError_t err__ = (call);                                                                 \
+    if (err__ != hipSuccess)                                                                   \
+      return fail(SMMC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__),     \
+                  __FILE__, __LINE__);                                                         \
+  } while (0)
+
+// Makes `device` current for the scope and restores the caller's device after.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+constexpr uint32_t kBlocksPerCU = 8;        // 8 x 4 waves = the CU's 32 wave slots
+constexpr uint64_t kHostChunkPaths = 1ull << 24;  // simulate_to_host: 64 MiB of floats per chunk
+
+}  // namespace
+
+struct smmc_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipStream_t copy_stream = nullptr;  // lazily created, simulate_to_host only
+  uint32_t compute_units = 0;
+  uint32_t max_grid = 0;
+  size_t max_lds = 0;
+
+  float *d_table = nullptr;  // 100.0f + r
+  uint32_t table_len = 0;
+  float table_min_a = 0.f, table_max_a = 0.f;
+  bool table_finite = false;
+
+  smmc::BlockPartial *d_partials = nullptr;  // max_grid entries
+
+  // simulate_to_host staging
+  float *d_stage[2] = {nullptr, nullptr};
+  uint64_t stage_paths = 0;
+  void *d_stage_stats = nullptr;
+  size_t stage_stats_bytes = 0;
+  hipEvent_t ev_compute[2] = {nullptr, nullptr};
+  hipEvent_t ev_copy[2] = {nullptr, nullptr};
+
+  bool timing = false;
+  std::vector<hipEvent_t> ev_pool;  // pairs: start, stop
+  size_t ev_used = 0;
+};
+
+namespace {
+
+int check_sim(const smmc_engine *e, const smmc_sim *s) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  if (!s) return fail(SMMC_ERR_INVALID, "sim is NULL");
+  if (s->struct_size != sizeof(smmc_sim))
+    return fail(SMMC_ERR_INVALID, "smmc_sim.struct_size is %u, this library expects %zu", s->struct_size,
+                sizeof(smmc_sim));
+  if (s->mode != SMMC_MODE_TABLE && s->mode != SMMC_MODE_GAUSSIAN)
+    return fail(SMMC_ERR_INVALID, "unknown mode %d", s->mode);
+  if (s->mode == SMMC_MODE_TABLE && e->table_len == 0)
+    return fail(SMMC_ERR_INVALID, "table mode needs smmc_engine_set_table first");
+  if (s->n_bins > SMMC_MAX_BINS)
+    return fail(SMMC_ERR_INVALID, "n_bins %u exceeds SMMC_MAX_BINS %d", s->n_bins, SMMC_MAX_BINS);
+  if (s->n_bins && !(s->hist_lo < s->hist_hi))
+    return fail(SMMC_ERR_INVALID, "histogram range must satisfy lo < hi (got %g, %g)", s->hist_lo, s->hist_hi);
+  if (s->n_bins && (!std::isfinite(s->hist_lo) || !std::isfinite(s->hist_hi)))
+    return fail(SMMC_ERR_INVALID, "histogram range must be finite");
+  if (s->n_paths > (1ull << 62)) return fail(SMMC_ERR_INVALID, "n_paths too large");
+  return SMMC_OK;
+}
+
+// The reciprocal-multiply divide is exact for |x| >= 2^-124 (and x = +0); pick it only
+// if no intermediate of any path can leave [2^-100, 2^100] or change sign.
+bool fast_div_is_safe(const smmc_engine *e, const smmc_sim *s) {
+  if (s->flags & SMMC_FLAG_EXACT_DIV) return false;
+  const double cap = s->initial_capital;
+  if (!(cap > 0.0) || !std::isfinite(cap)) return false;
+  double lo_a, hi_a;
+  if (s->mode == SMMC_MODE_TABLE) {
+    if (!e->table_finite) return false;
+    lo_a = e->table_min_a;
+    hi_a = e->table_max_a;
+  } else {
+    if (!std::isfinite(s->gauss_mean) || !std::isfinite(s->gauss_std)) return false;
+    // |z| <= sqrt(-2 ln 2^-33) * (1 + eps) < 6.8; 7 leaves margin for the roundings
+    const double spread = 7.0 * std::fabs(static_cast<double>(s->gauss_std));
+    lo_a = 100.0 + s->gauss_mean - spread - 1e-3;
+    hi_a = 100.0 + s->gauss_mean + spread + 1e-3;
+  }
+  if (!(lo_a > 0.0) || !std::isfinite(hi_a)) return false;
+  const double p = static_cast<double>(s->n_periods);
+  // after k periods: cap * prod(a/100) (the product total*a is 100x larger: +7 bits)
+  const double up = std::log2(cap) + p * std::max(0.0, std::log2(hi_a / 100.0)) + 7.0;
+  const double dn = std::log2(cap) + p * std::min(0.0, std::log2(lo_a / 100.0)) - 7.0;
+  return up < 100.0 && dn > -100.0;
+}
+
+smmc::KernelArgs make_args(const smmc_engine *e, const smmc_sim *s) {
+  smmc::KernelArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.mode = s->mode;
+  a.table_a = s->mode == SMMC_MODE_TABLE ? e->d_table : nullptr;
+  a.table_len = s->mode == SMMC_MODE_TABLE ? e->table_len : 0u;
+  a.key0 = static_cast<uint32_t>(s->seed);
+  a.key1 = static_cast<uint32_t>(s->seed >> 32);
+  a.first_path = s->first_path;
+  a.n_paths = s->n_paths;
+  a.n_periods = s->n_periods;
+  a.initial_capital = s->initial_capital;
+  a.gauss_mean = s->gauss_mean;
+  a.gauss_std = s->gauss_std;
+  a.n_bins = s->n_bins;
+  a.hist_lo = s->hist_lo;
+  a.hist_hi = s->hist_hi;
+  a.hist_inv = s->n_bins ? static_cast<double>(s->n_bins) /
+                               (static_cast<double>(s->hist_hi) - static_cast<double>(s->hist_lo))
+                         : 0.0;
+  a.below_threshold = s->below_threshold;
+  return a;
+}
+
+int timing_begin(smmc_engine *e) {
+  if (!e->timing) return SMMC_OK;
+  if (e->ev_used + 2 > e->ev_pool.size()) {
+    for (int i = 0; i < 2; ++i) {
+      hipEvent_t ev;
+      SMMC_HIP(hipEventCreate(&ev));
+      e->ev_pool.push_back(ev);
+    }
+  }
+  SMMC_HIP(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
+  return SMMC_OK;
+}
+int timing_end(smmc_engine *e) {
+  if (!e->timing) return SMMC_OK;
+  SMMC_HIP(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
+  e->ev_used += 2;
+  return SMMC_OK;
+}
+
+// Enqueue: (zero record) -> paths kernel -> finalize.  Device must be current.
+int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float *d_chunk_mean,
+                       float *d_chunk_var, void *d_stats) {
+  smmc::KernelArgs a = make_args(e, s);
+  a.d_final = d_final;
+  a.d_chunk_mean = d_chunk_mean;
+  a.d_chunk_var = d_chunk_var;
+  const uint64_t n_chunks = (s->n_paths + smmc::kBlock - 1) / smmc::kBlock;
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid));
+  if (d_stats) {
+    SMMC_HIP(hipMemsetAsync(d_stats, 0, smmc_stats_bytes(s->n_bins), e->stream));
+    a.partials = e->d_partials;
+    a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
+  }
+  if (grid > 0) {
+    const size_t lds = smmc::paths_lds_bytes(a.table_len, d_stats ? s->n_bins : 0u);
+    if (lds + 1024 > e->max_lds)
+      return fail(SMMC_ERR_INVALID, "table + histogram need %zu bytes of LDS, device allows %zu", lds, e->max_lds);
+    int rc = timing_begin(e);
+    if (rc) return rc;
+    SMMC_HIP(smmc::launch_paths(a, !fast_div_is_safe(e, s), grid, lds, e->stream));
+    rc = timing_end(e);
+    if (rc) return rc;
+  }
+  if (d_stats)
+    SMMC_HIP(smmc::launch_finalize(e->d_partials, grid, static_cast<smmc_stats *>(d_stats), s->n_bins, e->stream));
+  return SMMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smmc_abi_version(void) { return SMMC_ABI_VERSION; }
+const char *smmc_last_error(void) { return g_err; }
+
+float smmc_update_fund(float fund_value, float period_return) {
+  // reference src/simulations.cpp:14-16; this TU is built with -ffp-contract=off
+  const float a = 100.0f + period_return;
+  const float m = fund_value * a;
+  return m / 100.0f;
+}
+
+void smmc_many_updates(const float *returns, float *totals, uint32_t n_periods) {
+  // reference src/simulations.cpp:18-22
+  float t = totals[0];
+  for (uint32_t i = 0; i < n_periods; ++i) {
+    t = smmc_update_fund(t, returns[i]);
+    totals[i + 1] = t;
+  }
+}
+
+int smmc_device_count(int *count) {
+  if (!count) return fail(SMMC_ERR_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t err = hipGetDeviceCount(&n);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return SMMC_OK;
+}
+
+int smmc_engine_create(int device, void *stream, smmc_engine **out) {
+  if (!out) return fail(SMMC_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    (void)hipGetLastError();
+    return fail(SMMC_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+  }
+  if (device < 0 || device >= n) return fail(SMMC_ERR_INVALID, "device %d out of range [0, %d)", device, n);
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", device);
+  hipDeviceProp_t prop;
+  SMMC_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SMMC_ERR_NO_DEVICE, "device %d is %s; this library only carries gfx950 code", device, prop.gcnArchName);
+  smmc_engine *e = new (std::nothrow) smmc_engine();
+  if (!e) return fail(SMMC_ERR_NOMEM, "out of host memory");
+  e->device = device;
+  e->compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
+  e->max_grid = e->compute_units * kBlocksPerCU;
+  e->max_lds = prop.sharedMemPerBlock;
+  if (stream != SMMC_STREAM_NEW) {
+    e->stream = static_cast<hipStream_t>(stream);  // NULL = the default stream
+  } else {
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+      delete e;
+      return fail(SMMC_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(err));
+    }
+    e->own_stream = true;
+  }
+  hipError_t err = hipMalloc(reinterpret_cast<void **>(&e->d_partials), sizeof(smmc::BlockPartial) * e->max_grid);
+  if (err != hipSuccess) {
+    smmc_engine_destroy(e);
+    return fail(SMMC_ERR_HIP, "hipMalloc(partials) failed: %s", hipGetErrorString(err));
+  }
+  *out = e;
+  return SMMC_OK;
+}
+
+void smmc_engine_destroy(smmc_engine *e) {
+  if (!e) return;
+  DeviceGuard guard(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  if (e->copy_stream) {
+    (void)hipStreamSynchronize(e->copy_stream);
+    (void)hipStreamDestroy(e->copy_stream);
+  }
+  for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+  for (int i = 0; i < 2; ++i) {
+    if (e->ev_compute[i]) (void)hipEventDestroy(e->ev_compute[i]);
+    if (e->ev_copy[i]) (void)hipEventDestroy(e->ev_copy[i]);
+    if (e->d_stage[i]) (void)hipFree(e->d_stage[i]);
+  }
+  if (e->d_stage_stats) (void)hipFree(e->d_stage_stats);
+  if (e->d_table) (void)hipFree(e->d_table);
+  if (e->d_partials) (void)hipFree(e->d_partials);
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int smmc_engine_set_table(smmc_engine *e, const float *returns_percent, uint32_t n) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  if (!returns_percent || n == 0) return fail(SMMC_ERR_INVALID, "empty returns table");
+  if (n > SMMC_MAX_TABLE) return fail(SMMC_ERR_INVALID, "table of %u entries exceeds SMMC_MAX_TABLE %d", n, SMMC_MAX_TABLE);
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  // a = 100.0f + r: the first of update_fund's three roundings, hoisted out of the loop
+  std::vector<float> a(n);
+  float lo = std::numeric_limits<float>::infinity(), hi = -lo;
+  bool finite = true;
+  for (uint32_t i = 0; i < n; ++i) {
+    a[i] = 100.0f + returns_percent[i];
+    finite = finite && std::isfinite(a[i]);
+    lo = std::min(lo, a[i]);
+    hi = std::max(hi, a[i]);
+  }
+  if (e->table_len != n) {
+    // the previous table may still be read by enqueued kernels
+    SMMC_HIP(hipStreamSynchronize(e->stream));
+    if (e->d_table) SMMC_HIP(hipFree(e->d_table));
+    e->d_table = nullptr;
+    e->table_len = 0;
+    SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_table), sizeof(float) * n));
+  }
+  SMMC_HIP(hipMemcpyAsync(e->d_table, a.data(), sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
+  SMMC_HIP(hipStreamSynchronize(e->stream));  // `a` is a local
+  e->table_len = n;
+  e->table_min_a = lo;
+  e->table_max_a = hi;
+  e->table_finite = finite;
+  return SMMC_OK;
+}
+
+int smmc_engine_simulate(smmc_engine *e, const smmc_sim *sim, float *d_final, float *d_chunk_mean,
+                         float *d_chunk_var, void *d_stats) {
+  int rc = check_sim(e, sim);
+  if (rc) return rc;
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  return enqueue_simulation(e, sim, d_final, d_chunk_mean, d_chunk_var, d_stats);
+}
+
+int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_traj, float *d_final) {
+  int rc = check_sim(e, sim);
+  if (rc) return rc;
+  if (!d_traj) return fail(SMMC_ERR_INVALID, "d_traj is NULL");
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  smmc::KernelArgs a = make_args(e, sim);
+  a.d_traj = d_traj;
+  a.d_final = d_final;
+  const uint64_t n_chunks = (sim->n_paths + smmc::kBlock - 1) / smmc::kBlock;
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid));
+  if (grid == 0) return SMMC_OK;
+  const size_t lds = smmc::keepdata_lds_bytes(a.table_len);
+  if (lds > e->max_lds)
+    return fail(SMMC_ERR_INVALID, "keepdata needs %zu bytes of LDS, device allows %zu", lds, e->max_lds);
+  rc = timing_begin(e);
+  if (rc) return rc;
+  SMMC_HIP(smmc::launch_keepdata(a, !fast_div_is_safe(e, sim), grid, lds, e->stream));
+  return timing_end(e);
+}
+
+int smmc_engine_sync(smmc_engine *e) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  DeviceGuard guard(e->device);
+  SMMC_HIP(hipStreamSynchronize(e->stream));
+  return SMMC_OK;
+}
+
+int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *host_final,
+                                 volatile int64_t *progress, smmc_stats *stats, uint64_t *hist) {
+  int rc = check_sim(e, sim);
+  if (rc) return rc;
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  const uint64_t n = sim->n_paths;
+  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), kHostChunkPaths);
+  const uint64_t n_chunks = (n + chunk - 1) / chunk;
+  const bool want_stats = stats != nullptr || hist != nullptr;
+  const size_t rec = smmc_stats_bytes(sim->n_bins);
+
+  if (!e->copy_stream) SMMC_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    if (!e->ev_compute[i]) SMMC_HIP(hipEventCreateWithFlags(&e->ev_compute[i], hipEventDisableTiming));
+    if (!e->ev_copy[i]) SMMC_HIP(hipEventCreateWithFlags(&e->ev_copy[i], hipEventDisableTiming));
+  }
+  if (host_final && e->stage_paths < chunk) {
+    for (int i = 0; i < 2; ++i) {
+      if (e->d_stage[i]) SMMC_HIP(hipFree(e->d_stage[i]));
+      e->d_stage[i] = nullptr;
+    }
+    e->stage_paths = 0;
+    for (int i = 0; i < 2; ++i) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_stage[i]), sizeof(float) * chunk));
+    e->stage_paths = chunk;
+  }
+  if (want_stats && e->stage_stats_bytes < rec * std::max<uint64_t>(n_chunks, 1)) {
+    if (e->d_stage_stats) SMMC_HIP(hipFree(e->d_stage_stats));
+    e->d_stage_stats = nullptr;
+    e->stage_stats_bytes = 0;
+    SMMC_HIP(hipMalloc(&e->d_stage_stats, rec * std::max<uint64_t>(n_chunks, 1)));
+    e->stage_stats_bytes = rec * std::max<uint64_t>(n_chunks, 1);
+  }
+  if (progress) *progress = 0;
+
+  // Pipeline: the kernel of chunk c (engine stream) overlaps the D2H copy of chunk
+  // c - 1 (copy stream).  Buffer b = c & 1 is reused once its copy has finished.
+  for (uint64_t c = 0; c < n_chunks; ++c) {
+    const int b = static_cast<int>(c & 1);
+    smmc_sim part = *sim;
+    part.first_path = sim->first_path + c * chunk;
+    part.n_paths = std::min<uint64_t>(chunk, n - c * chunk);
+    if (c >= 2) SMMC_HIP(hipStreamWaitEvent(e->stream, e->ev_copy[b], 0));
+    void *d_rec = want_stats ? static_cast<char *>(e->d_stage_stats) + rec * c : nullptr;
+    rc = enqueue_simulation(e, &part, host_final ? e->d_stage[b] : nullptr, nullptr, nullptr, d_rec);
+    if (rc) return rc;
+    if (host_final) {
+      SMMC_HIP(hipEventRecord(e->ev_compute[b], e->stream));
+      SMMC_HIP(hipStreamWaitEvent(e->copy_stream, e->ev_compute[b], 0));
+      SMMC_HIP(hipMemcpyAsync(host_final + c * chunk, e->d_stage[b], sizeof(float) * part.n_paths,
+                              hipMemcpyDeviceToHost, e->copy_stream));
+      SMMC_HIP(hipEventRecord(e->ev_copy[b], e->copy_stream));
+      if (progress && c >= 1) {
+        SMMC_HIP(hipEventSynchronize(e->ev_copy[b ^ 1]));
+        *progress = static_cast<int64_t>(c * chunk);
+      }
+    }
+  }
+  SMMC_HIP(hipStreamSynchronize(e->stream));
+  if (host_final) SMMC_HIP(hipStreamSynchronize(e->copy_stream));
+  if (progress) *progress = static_cast<int64_t>(n);
+
+  if (want_stats) {
+    std::vector<char> all(rec * std::max<uint64_t>(n_chunks, 1));
+    std::vector<char> acc(rec, 0);
+    smmc_stats *h = reinterpret_cast<smmc_stats *>(acc.data());
+    h->min = std::numeric_limits<float>::infinity();
+    h->max = -std::numeric_limits<float>::infinity();
+    h->n_bins = sim->n_bins;
+    if (n_chunks) {
+      SMMC_HIP(hipMemcpy(all.data(), e->d_stage_stats, rec * n_chunks, hipMemcpyDeviceToHost));
+      for (uint64_t c = 0; c < n_chunks; ++c) {
+        rc = smmc_stats_merge(acc.data(), all.data() + rec * c);
+        if (rc) return rc;
+      }
+    }
+    if (stats) *stats = *h;
+    if (hist && sim->n_bins) std::memcpy(hist, acc.data() + sizeof(smmc_stats), sizeof(uint64_t) * sim->n_bins);
+  }
+  return SMMC_OK;
+}
+
+int smmc_engine_timing(smmc_engine *e, int enable) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  e->timing = enable != 0;
+  return SMMC_OK;
+}
+
+int smmc_engine_kernel_ms(smmc_engine *e, double *total_ms, uint32_t *launches) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  DeviceGuard guard(e->device);
+  SMMC_HIP(hipStreamSynchronize(e->stream));
+  double total = 0.0;
+  for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+    float ms = 0.f;
+    SMMC_HIP(hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));
+    total += ms;
+  }
+  if (total_ms) *total_ms = total;
+  if (launches) *launches = static_cast<uint32_t>(e->ev_used / 2);
+  e->ev_used = 0;
+  return SMMC_OK;
+}
+
+int smmc_engine_geometry(smmc_engine *e, uint32_t *grid, uint32_t *block, uint32_t *compute_units) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  if (grid) *grid = e->max_grid;
+  if (block) *block = smmc::kBlock;
+  if (compute_units) *compute_units = e->compute_units;
+  return SMMC_OK;
+}
+
+uint64_t smmc_stats_bytes(uint32_t n_bins) { return sizeof(smmc_stats) + sizeof(uint64_t) * n_bins; }
+
+int smmc_stats_merge(void *dst_packed, const void *src_packed) {
+  if (!dst_packed || !src_packed) return fail(SMMC_ERR_INVALID, "NULL statistics record");
+  smmc_stats *d = static_cast<smmc_stats *>(dst_packed);
+  const smmc_stats *s = static_cast<const smmc_stats *>(src_packed);
+  if (d->n_bins != s->n_bins) return fail(SMMC_ERR_INVALID, "records have %u and %u bins", d->n_bins, s->n_bins);
+  d->count += s->count;
+  d->below += s->below;
+  d->underflow += s->underflow;
+  d->overflow += s->overflow;
+  d->sum += s->sum;
+  d->sumsq += s->sumsq;
+  d->min = std::min(d->min, s->min);
+  d->max = std::max(d->max, s->max);
+  uint64_t *dh = reinterpret_cast<uint64_t *>(d + 1);
+  const uint64_t *sh = reinterpret_cast<const uint64_t *>(s + 1);
+  for (uint32_t i = 0; i < d->n_bins; ++i) dh[i] += sh[i];
+  return SMMC_OK;
+}
+
+}  // extern "C"

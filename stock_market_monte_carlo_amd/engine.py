@@ -1,0 +1,313 @@
+"""Host-side mirror of the reference's Monte-Carlo API on top of the C ABI.
+
+Function names, argument meaning and error behaviour follow
+include/stock_market_monte_carlo/simulations.h of the reference (cited per function);
+the work happens in libsmmc_hip.so on the MI355X.  PyTorch only provides device
+memory and the stream.
+"""
+import ctypes as C
+import dataclasses
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import MODE_GAUSSIAN, MODE_TABLE, SmmcError
+
+DEFAULT_TABLE_CSV = "data/SP500_monthly_returns.csv"  # examples/benchmark_mc_cpu_v2.cpp:25
+
+
+@dataclasses.dataclass
+class Stats:
+    """Host copy of a packed statistics record (smmc_stats + bucket counts)."""
+    count: int
+    below: int
+    underflow: int
+    overflow: int
+    sum: float
+    sumsq: float
+    min: float
+    max: float
+    hist: np.ndarray
+
+    @property
+    def mean(self):
+        return self.sum / self.count if self.count else float("nan")
+
+    @property
+    def std(self):
+        """Population standard deviation (examples/benchmark_mc_gpu.cpp:19-27)."""
+        if not self.count:
+            return float("nan")
+        m = self.mean
+        return max(self.sumsq / self.count - m * m, 0.0) ** 0.5
+
+
+def stats_from_bytes(raw):
+    """raw: bytes/uint8 array holding one packed record."""
+    buf = np.frombuffer(bytes(raw), dtype=np.uint8)
+    hdr = _lib.Stats.from_buffer_copy(buf[: C.sizeof(_lib.Stats)].tobytes())
+    hist = np.frombuffer(buf[C.sizeof(_lib.Stats):].tobytes(), dtype=np.uint64)[: hdr.n_bins].copy()
+    return Stats(hdr.count, hdr.below, hdr.underflow, hdr.overflow, hdr.sum, hdr.sumsq, hdr.min, hdr.max, hist)
+
+
+def merge_stats_bytes(records):
+    """Merges packed records (same n_bins) in the given order; returns bytes."""
+    L = _lib.lib()
+    acc = bytearray(records[0])
+    dst = (C.c_char * len(acc)).from_buffer(acc)
+    for r in records[1:]:
+        src = (C.c_char * len(r)).from_buffer_copy(bytes(r))
+        _lib.check(L.smmc_stats_merge(dst, src))
+    return bytes(acc)
+
+
+@dataclasses.dataclass
+class SimResult:
+    final: object = None        # torch.float32 [n_paths] on the engine's device, or None
+    chunk_mean: object = None   # torch.float32 [ceil(n/256)] or None
+    chunk_var: object = None
+    stats_raw: object = None    # torch.uint8 [smmc_stats_bytes(n_bins)] on device, or None
+
+
+class Engine:
+    """One engine per (process, device): table, workspace and stream stay resident."""
+
+    def __init__(self, device=0, stream="torch"):
+        import torch
+        self._torch = torch
+        self._L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise SmmcError("no MI355X visible to this process; the engine has no CPU fallback")
+        self.device = int(device)
+        self.tdevice = torch.device("cuda", self.device)
+        # "torch": launch on torch's current stream of that device (handle 0 = the default
+        # stream), so tensors produced here are ordered with the caller's torch work;
+        # "new": an engine-owned non-blocking stream; or a raw hipStream_t handle.
+        if stream == "torch":
+            sp = int(torch.cuda.current_stream(self.tdevice).cuda_stream)
+        elif stream == "new":
+            sp = -1  # SMMC_STREAM_NEW
+        else:
+            sp = int(stream)
+        self.own_stream = sp == -1
+        h = C.c_void_p()
+        _lib.check(self._L.smmc_engine_create(self.device, C.c_void_p(sp), C.byref(h)))
+        self._h = h
+        self.table_len = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.smmc_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration -------------------------------------------------------
+    def set_table(self, returns_percent):
+        t = np.ascontiguousarray(returns_percent, dtype=np.float32)
+        _lib.check(self._L.smmc_engine_set_table(self._h, t.ctypes.data_as(C.c_void_p), t.size))
+        self.table_len = int(t.size)
+
+    def geometry(self):
+        g, b, cu = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.check(self._L.smmc_engine_geometry(self._h, C.byref(g), C.byref(b), C.byref(cu)))
+        return g.value, b.value, cu.value
+
+    def timing(self, enable=True):
+        _lib.check(self._L.smmc_engine_timing(self._h, 1 if enable else 0))
+
+    def kernel_ms(self):
+        """(summed main-kernel milliseconds, launches) since the last call; synchronises."""
+        ms, n = C.c_double(), C.c_uint32()
+        _lib.check(self._L.smmc_engine_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def sync(self):
+        _lib.check(self._L.smmc_engine_sync(self._h))
+
+    # -- simulation ----------------------------------------------------------
+    @staticmethod
+    def make_sim(n_paths, n_periods, mode, seed, first_path=0, initial_capital=1000.0, gauss_mean=0.5,
+                 gauss_std=0.83333, n_bins=0, hist_lo=0.0, hist_hi=1.0, below_threshold=None,
+                 exact_div=False):
+        s = _lib.Sim()
+        s.struct_size = C.sizeof(_lib.Sim)
+        s.mode = mode
+        s.seed = seed & 0xFFFFFFFFFFFFFFFF
+        s.first_path = first_path
+        s.n_paths = n_paths
+        s.n_periods = n_periods
+        s.initial_capital = initial_capital
+        s.gauss_mean = gauss_mean
+        s.gauss_std = gauss_std
+        s.n_bins = n_bins
+        s.hist_lo = hist_lo
+        s.hist_hi = hist_hi
+        s.below_threshold = initial_capital if below_threshold is None else below_threshold
+        s.flags = _lib.FLAG_EXACT_DIV if exact_div else 0
+        return s
+
+    def simulate(self, sim, want_final=True, want_chunk_stats=False, want_stats=False, out=None):
+        """Enqueues one simulation on the engine stream; returns device tensors."""
+        torch = self._torch
+        n = int(sim.n_paths)
+        res = SimResult()
+        if want_final:
+            res.final = out if out is not None else torch.empty(n, dtype=torch.float32, device=self.tdevice)
+            assert res.final.numel() >= n and res.final.dtype == torch.float32 and res.final.is_contiguous()
+        if want_chunk_stats:
+            nc = (n + _lib.CHUNK - 1) // _lib.CHUNK
+            res.chunk_mean = torch.empty(nc, dtype=torch.float32, device=self.tdevice)
+            res.chunk_var = torch.empty(nc, dtype=torch.float32, device=self.tdevice)
+        if want_stats:
+            res.stats_raw = torch.empty(int(self._L.smmc_stats_bytes(sim.n_bins)), dtype=torch.uint8,
+                                        device=self.tdevice)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None  # noqa: E731
+        _lib.check(self._L.smmc_engine_simulate(self._h, C.byref(sim), ptr(res.final), ptr(res.chunk_mean),
+                                                ptr(res.chunk_var), ptr(res.stats_raw)))
+        return res
+
+    def read_stats(self, stats_raw):
+        """Copies a device record to the host after the engine stream has drained."""
+        self.sync()
+        return stats_from_bytes(stats_raw.cpu().numpy().tobytes())
+
+    def simulate_keepdata(self, sim, want_final=True):
+        torch = self._torch
+        n, p = int(sim.n_paths), int(sim.n_periods)
+        traj = torch.empty((n, p + 1), dtype=torch.float32, device=self.tdevice)
+        final = torch.empty(n, dtype=torch.float32, device=self.tdevice) if want_final else None
+        if n:
+            _lib.check(self._L.smmc_engine_simulate_keepdata(
+                self._h, C.byref(sim), C.c_void_p(traj.data_ptr()),
+                C.c_void_p(final.data_ptr()) if final is not None else None))
+        return traj, final
+
+    def simulate_to_host(self, sim, out=None, want_stats=False, progress=None):
+        """Final values straight into host memory (chunked, D2H overlapped with compute)."""
+        n = int(sim.n_paths)
+        host = out if out is not None else np.empty(n, dtype=np.float32)
+        assert host.dtype == np.float32 and host.size >= n and host.flags.c_contiguous
+        st = _lib.Stats()
+        hist = np.zeros(max(int(sim.n_bins), 1), dtype=np.uint64)
+        prog = progress if progress is not None else C.c_int64(0)
+        _lib.check(self._L.smmc_engine_simulate_to_host(
+            self._h, C.byref(sim), host.ctypes.data_as(C.c_void_p), C.byref(prog),
+            C.byref(st) if want_stats else None, hist.ctypes.data_as(C.c_void_p) if want_stats else None))
+        stats = None
+        if want_stats:
+            stats = Stats(st.count, st.below, st.underflow, st.overflow, st.sum, st.sumsq, st.min, st.max,
+                          hist[: int(sim.n_bins)])
+        return host, stats
+
+
+# ---------------------------------------------------------------------------
+# Reference-named functions (include/stock_market_monte_carlo/simulations.h)
+# ---------------------------------------------------------------------------
+
+_engines = {}
+
+
+def _engine(device=0):
+    e = _engines.get(device)
+    if e is None:
+        e = _engines[device] = Engine(device)
+    return e
+
+
+def _seed(seed):
+    # the reference seeds every path from std::random_device (src/simulations.cpp:245-246)
+    return int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)
+
+
+def update_fund(fund_value, period_return):
+    """simulations.h:9, src/simulations.cpp:14-16."""
+    return float(_lib.lib().smmc_update_fund(float(fund_value), float(period_return)))
+
+
+def many_updates(fund_value, returns, n_periods):
+    """simulations.h:11-13, src/simulations.cpp:24-39: n_periods + 1 values, [0] = fund_value."""
+    r = np.ascontiguousarray(returns, dtype=np.float32)
+    if r.size < n_periods:
+        raise ValueError("returns holds fewer than n_periods entries")
+    out = np.empty(n_periods + 1, dtype=np.float32)
+    out[0] = np.float32(fund_value)
+    _lib.lib().smmc_many_updates(r.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), n_periods)
+    return out
+
+
+def read_historical_returns(csv_fpath):
+    """simulations.h:31, src/simulations.cpp:83-93: the `returns` column of a CSV, percent units.
+    Rows whose cell is empty (first month of python/get_data.py:59 output) are skipped."""
+    vals = []
+    with open(csv_fpath) as f:
+        header = [h.strip() for h in f.readline().rstrip("\r\n").split(",")]
+        if "returns" not in header:
+            raise ValueError(f"{csv_fpath}: no column named 'returns'")
+        col = header.index("returns")
+        for line in f:
+            cells = line.rstrip("\r\n").split(",")
+            if col < len(cells) and cells[col].strip() not in ("", "nan", "NaN"):
+                vals.append(np.float32(cells[col]))
+    return np.array(vals, dtype=np.float32)
+
+
+def mc_simulations_gpu(max_n_simulations, n_periods, initial_capital, returns, n_gpus=1, seed=None):
+    """simulations.h:73-79, src/simulations.cu:661-680: final value of every path (host array).
+    Paths shard over n_gpus devices of this process by contiguous global id ranges."""
+    import torch
+    if n_gpus < 1 or n_gpus > torch.cuda.device_count():
+        raise ValueError(f"n_gpus={n_gpus} but {torch.cuda.device_count()} device(s) visible")
+    seed = _seed(seed)
+    n = int(max_n_simulations)
+    out = np.empty(n, dtype=np.float32)
+    base, extra = divmod(n, n_gpus)
+    first = 0
+    for g in range(n_gpus):
+        cnt = base + (1 if g < extra else 0)
+        e = _engine(g)
+        e.set_table(returns)
+        sim = Engine.make_sim(cnt, n_periods, MODE_TABLE, seed, first_path=first, initial_capital=initial_capital)
+        e.simulate_to_host(sim, out=out[first:first + cnt])
+        first += cnt
+    return out
+
+
+def mc_simulations(max_n_simulations, n_periods, initial_capital, historical_returns, final_values=None, seed=None):
+    """simulations.h:49-54, src/simulations.cpp:204-266 (the CPU v2 engine), run on the GPU.
+    final_values, if given, must be pre-sized like the reference's caller does
+    (examples/benchmark_mc_cpu_v2.cpp:26) and is filled in place."""
+    n = int(max_n_simulations)
+    if final_values is not None and (final_values.size < n or final_values.dtype != np.float32):
+        raise ValueError("final_values must be a float32 array of at least max_n_simulations entries")
+    e = _engine(0)
+    e.set_table(historical_returns)
+    sim = Engine.make_sim(n, n_periods, MODE_TABLE, _seed(seed), initial_capital=initial_capital)
+    out, _ = e.simulate_to_host(sim, out=final_values)
+    return out[:n]
+
+
+def mc_simulations_gpu_reduceBlock(max_n_simulations, n_periods, initial_capital, returns, n_gpus=1, seed=None):
+    """simulations.h:81-88, src/simulations.cu:682-697: (means, variances), one pair per 256 paths."""
+    if n_gpus != 1:
+        # src/simulations.cu:693 throws std::invalid_argument
+        raise ValueError("mc_simulations_gpu_reduceBlock supports n_gpus == 1 only")
+    e = _engine(0)
+    e.set_table(returns)
+    sim = Engine.make_sim(int(max_n_simulations), n_periods, MODE_TABLE, _seed(seed), initial_capital=initial_capital)
+    r = e.simulate(sim, want_final=False, want_chunk_stats=True)
+    return r.chunk_mean.cpu().numpy(), r.chunk_var.cpu().numpy()
+
+
+def mc_simulations_keepdata(max_n_simulations, n_periods, initial_capital, historical_returns, seed=None):
+    """simulations.h:57-63, src/simulations.cpp:139-202: (mc_data [N, P+1], final_values)."""
+    e = _engine(0)
+    e.set_table(historical_returns)
+    sim = Engine.make_sim(int(max_n_simulations), n_periods, MODE_TABLE, _seed(seed), initial_capital=initial_capital)
+    traj, final = e.simulate_keepdata(sim)
+    return traj.cpu().numpy(), final.cpu().numpy()

@@ -1,0 +1,278 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bit-exact for final values (binary32 patterns), histogram bucket counts and the
+below/underflow/overflow counters; sums (double) to 1e-12 relative because the
+device adds in a tree order; per-chunk mean/variance (float) to 1e-6 relative.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SEED = 0x5EED0123456789AB
+
+
+@pytest.fixture(scope="module")
+def eng(table):
+    import stock_market_monte_carlo_amd as S
+    e = S.Engine(0)
+    e.set_table(table)
+    yield e
+    e.close()
+
+
+def _modes():
+    from stock_market_monte_carlo_amd import MODE_GAUSSIAN, MODE_TABLE
+    return {"table": MODE_TABLE, "gaussian": MODE_GAUSSIAN}
+
+
+def _run_both(eng, oracle, table, mode, n, p, first=0, seed=SEED, n_bins=0, lo=0.0, hi=1.0, cap=1000.0,
+              mean=0.5, std=0.83333, exact_div=False, below=None):
+    from stock_market_monte_carlo_amd import Engine
+    sim = Engine.make_sim(n, p, mode, seed, first_path=first, initial_capital=cap, gauss_mean=mean, gauss_std=std,
+                          n_bins=n_bins, hist_lo=lo, hist_hi=hi, exact_div=exact_div, below_threshold=below)
+    r = eng.simulate(sim, want_final=True, want_chunk_stats=True, want_stats=True)
+    st = eng.read_stats(r.stats_raw)
+    op = oracle.make_params(mode, p, n, seed, first_path=first, initial_capital=cap, table=table, gauss_mean=mean,
+                            gauss_std=std, n_bins=n_bins, hist_lo=lo, hist_hi=hi,
+                            below_threshold=cap if below is None else below)
+    o = oracle.counter_mc(op)
+    return r, st, o
+
+
+@pytest.mark.parametrize("mode_name", ["table", "gaussian"])
+@pytest.mark.parametrize("p", [0, 1, 3, 4, 5, 7, 360, 1000])
+def test_final_values_bit_exact(eng, oracle, table, mode_name, p):
+    mode = _modes()[mode_name]
+    n = 5000 + 37  # ragged: not a multiple of 256
+    r, st, o = _run_both(eng, oracle, table, mode, n, p, n_bins=100, lo=0.0, hi=20000.0)
+    got = r.final.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), o["final"].view(np.uint32))
+    os_ = o["stats"]
+    assert st.count == n == os_.count
+    assert (st.below, st.underflow, st.overflow) == (os_.below, os_.underflow, os_.overflow)
+    assert np.array_equal(st.hist, o["hist"])
+    assert int(st.hist.sum()) + st.underflow + st.overflow == n
+    assert st.min == os_.min and st.max == os_.max
+    assert st.sum == pytest.approx(os_.sum, rel=1e-12)
+    assert st.sumsq == pytest.approx(os_.sumsq, rel=1e-12)
+    cm, cv = oracle.chunk_mean_var(o["final"])
+    np.testing.assert_allclose(r.chunk_mean.cpu().numpy(), cm, rtol=1e-6)
+    np.testing.assert_allclose(r.chunk_var.cpu().numpy(), cv, rtol=1e-5, atol=1e-6 * float(np.max(cv) + 1))
+
+
+@pytest.mark.parametrize("mode_name", ["table", "gaussian"])
+def test_path_ids_beyond_32_bits_and_seed_halves(eng, oracle, table, mode_name):
+    mode = _modes()[mode_name]
+    for first, seed in [((1 << 32) - 100, SEED), ((1 << 40) + 12345, 1), (7, 0xFFFFFFFF00000000)]:
+        r, _, o = _run_both(eng, oracle, table, mode, 700, 36, first=first, seed=seed)
+        assert np.array_equal(r.final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32)), (first, seed)
+
+
+def test_golden_counter_stream(eng, table):
+    """Frozen oracle outputs (tests/golden/counter_stream_v1.json, made by make_golden.py)."""
+    from stock_market_monte_carlo_amd import Engine
+    with open(os.path.join(HERE, "golden", "counter_stream_v1.json")) as f:
+        gold = json.load(f)
+    for c in gold["cases"]:
+        sim = Engine.make_sim(c["n_paths"], c["n_periods"], _modes()[c["mode"]], c["seed"], first_path=c["first_path"],
+                              initial_capital=c["initial_capital"], gauss_mean=c["gauss_mean"], gauss_std=c["gauss_std"],
+                              n_bins=c["n_bins"], hist_lo=c["hist_lo"], hist_hi=c["hist_hi"],
+                              below_threshold=c["below_threshold"])
+        r = eng.simulate(sim, want_stats=True)
+        st = eng.read_stats(r.stats_raw)
+        assert [int(x) for x in r.final.cpu().numpy().view(np.uint32)] == c["final_bits"], (c["mode"], c["n_periods"])
+        assert [int(x) for x in st.hist] == c["hist"]
+        assert (st.below, st.underflow, st.overflow) == (c["below"], c["underflow"], c["overflow"])
+
+
+@pytest.mark.parametrize("mode_name", ["table", "gaussian"])
+def test_exact_divide_variant_matches_fast_variant(eng, oracle, table, mode_name):
+    mode = _modes()[mode_name]
+    a, _, o = _run_both(eng, oracle, table, mode, 3000, 360, exact_div=False)
+    b, _, _ = _run_both(eng, oracle, table, mode, 3000, 360, exact_div=True)
+    assert np.array_equal(a.final.cpu().numpy().view(np.uint32), b.final.cpu().numpy().view(np.uint32))
+    assert np.array_equal(b.final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32))
+
+
+def test_out_of_range_trajectories_take_the_ieee_divide(eng, oracle):
+    """Huge swings push values past 2^100 / to inf and 0: the host must pick the exact-divide
+    kernel, and results must still equal the oracle bit for bit (inf and 0 included)."""
+    from stock_market_monte_carlo_amd import MODE_TABLE
+    wild = np.array([9000.0, -99.9, 50000.0, -100.0, 3.0e6, -50.0, 10.0], dtype=np.float32)
+    eng.set_table(wild)
+    try:
+        r, st, o = _run_both(eng, oracle, wild, MODE_TABLE, 2000, 60, cap=1.0e-20, n_bins=10, lo=0.0, hi=1.0e30)
+        got = r.final.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), o["final"].view(np.uint32))
+        assert np.array_equal(st.hist, o["hist"]) and st.overflow == o["stats"].overflow
+    finally:
+        from conftest import load_table
+        eng.set_table(load_table())
+
+
+def test_histogram_edges_and_single_bin(eng, oracle, table):
+    from stock_market_monte_carlo_amd import MODE_TABLE
+    # narrow range: most values under/overflow; 1 bin; 4096 bins
+    for n_bins, lo, hi in [(1, 900.0, 1100.0), (4096, 0.0, 50000.0), (7, 5000.0, 5000.5), (100, -10.0, 1.0)]:
+        _, st, o = _run_both(eng, oracle, table, MODE_TABLE, 4000, 120, n_bins=n_bins, lo=lo, hi=hi, below=5000.0)
+        assert np.array_equal(st.hist, o["hist"]), (n_bins, lo, hi)
+        assert (st.below, st.underflow, st.overflow) == (o["stats"].below, o["stats"].underflow, o["stats"].overflow)
+
+
+def test_sharding_is_invisible(eng, table):
+    """A path's value depends on (seed, global id) only: shards concatenate to the whole."""
+    from stock_market_monte_carlo_amd import Engine, MODE_GAUSSIAN
+    from stock_market_monte_carlo_amd.engine import merge_stats_bytes, stats_from_bytes
+    n = 100003
+    whole = eng.simulate(Engine.make_sim(n, 48, MODE_GAUSSIAN, 99, n_bins=64, hist_lo=0, hist_hi=5000), want_stats=True)
+    parts, recs = [], []
+    cuts = [0, 1, 256, 33333, 33334, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        r = eng.simulate(Engine.make_sim(b - a, 48, MODE_GAUSSIAN, 99, first_path=a, n_bins=64, hist_lo=0, hist_hi=5000),
+                         want_stats=True)
+        parts.append(r.final.cpu().numpy())
+        recs.append(r.stats_raw.cpu().numpy().tobytes())
+    assert np.array_equal(np.concatenate(parts).view(np.uint32), whole.final.cpu().numpy().view(np.uint32))
+    merged = stats_from_bytes(merge_stats_bytes(recs))
+    w = eng.read_stats(whole.stats_raw)
+    assert merged.count == w.count == n and np.array_equal(merged.hist, w.hist)
+    assert (merged.below, merged.underflow, merged.overflow) == (w.below, w.underflow, w.overflow)
+    assert merged.min == w.min and merged.max == w.max
+    assert merged.sum == pytest.approx(w.sum, rel=1e-12)
+
+
+def test_empty_and_tiny(eng, table):
+    from stock_market_monte_carlo_amd import Engine, MODE_TABLE
+    r = eng.simulate(Engine.make_sim(0, 360, MODE_TABLE, 1, n_bins=10, hist_lo=0, hist_hi=10), want_stats=True,
+                     want_chunk_stats=True)
+    st = eng.read_stats(r.stats_raw)
+    assert st.count == 0 and st.hist.sum() == 0 and st.min == float("inf") and st.max == float("-inf")
+    assert r.final.numel() == 0 and r.chunk_mean.numel() == 0
+    r = eng.simulate(Engine.make_sim(1, 0, MODE_TABLE, 1, initial_capital=123.5))
+    assert r.final.cpu().numpy().tolist() == [123.5]
+
+
+def test_table_of_one_entry_is_deterministic_compounding(eng, oracle):
+    from stock_market_monte_carlo_amd import Engine, MODE_TABLE
+    from conftest import load_table
+    eng.set_table(np.array([1.5], dtype=np.float32))
+    try:
+        r = eng.simulate(Engine.make_sim(300, 25, MODE_TABLE, 5))
+        want = oracle.many_updates(1000.0, np.full(25, 1.5, dtype=np.float32), 25)[-1]
+        assert np.all(r.final.cpu().numpy().view(np.uint32) == np.float32(want).view(np.uint32))
+    finally:
+        eng.set_table(load_table())
+
+
+@pytest.mark.parametrize("mode_name", ["table", "gaussian"])
+def test_keepdata_trajectories_bit_exact(eng, oracle, table, mode_name):
+    from stock_market_monte_carlo_amd import Engine
+    mode = _modes()[mode_name]
+    for n, p in [(300, 360), (1000, 1), (257, 64), (64, 65), (700, 130)]:
+        sim = Engine.make_sim(n, p, mode, SEED, first_path=11)
+        traj, final = eng.simulate_keepdata(sim)
+        op = oracle.make_params(mode, p, n, SEED, first_path=11, table=table)
+        o = oracle.counter_mc(op, want_traj=True)
+        assert np.array_equal(traj.cpu().numpy().view(np.uint32), o["traj"].view(np.uint32)), (n, p)
+        assert np.array_equal(final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32))
+        # the trajectory IS many_updates of the path's draws (src/simulations.cpp:175-186)
+        rets = oracle.counter_path_returns(op, 11 + n - 1)
+        assert np.array_equal(oracle.many_updates(1000.0, rets, p).view(np.uint32),
+                              traj[n - 1].cpu().numpy().view(np.uint32))
+
+
+def test_simulate_to_host_pipeline_matches_device_path(eng, table):
+    """More than one 16 Mi-path chunk through the overlapped D2H pipeline."""
+    from stock_market_monte_carlo_amd import Engine, MODE_TABLE
+    n = (1 << 24) * 2 + 12345
+    sim = Engine.make_sim(n, 4, MODE_TABLE, 3, n_bins=50, hist_lo=800, hist_hi=1300)
+    host, st = eng.simulate_to_host(sim, want_stats=True)
+    dev = eng.simulate(sim, want_stats=True)
+    assert np.array_equal(host.view(np.uint32), dev.final.cpu().numpy().view(np.uint32))
+    w = eng.read_stats(dev.stats_raw)
+    assert st.count == n and np.array_equal(st.hist, w.hist) and st.below == w.below
+    assert st.sum == pytest.approx(w.sum, rel=1e-12)
+
+
+def test_full_size_properties(eng, table):
+    """BASELINE configs 2/3 size (1e8 paths x 360): properties that need no oracle."""
+    from stock_market_monte_carlo_amd import Engine, MODE_GAUSSIAN, MODE_TABLE
+    n = 100_000_000
+    for mode in (MODE_TABLE, MODE_GAUSSIAN):
+        sim = Engine.make_sim(n, 360, mode, SEED, n_bins=100, hist_lo=0.0, hist_hi=20000.0)
+        a = eng.simulate(sim, want_final=True, want_stats=True)
+        st = eng.read_stats(a.stats_raw)
+        assert st.count == n and int(st.hist.sum()) + st.underflow + st.overflow == n
+        # the statistics kernel path and the final values agree
+        fin = a.final
+        assert int((fin < 1000.0).sum().item()) == st.below
+        assert float(fin.min().item()) == st.min and float(fin.max().item()) == st.max
+        assert float(fin.double().sum().item()) == pytest.approx(st.sum, rel=1e-11)
+        # run-to-run determinism (integer checksum of all bit patterns)
+        b = eng.simulate(sim, want_final=True)
+        import torch
+        assert torch.equal(a.final.view(torch.int32), b.final.view(torch.int32))
+        # spot check against the oracle: the last 300 paths
+        del b
+    from oracle import oracle as O
+    sim = Engine.make_sim(n, 360, MODE_TABLE, SEED)
+    a = eng.simulate(sim)
+    tail = a.final[-300:].cpu().numpy()
+    op = O.make_params(O.MODE_TABLE, 360, 300, SEED, first_path=n - 300, table=table)
+    assert np.array_equal(tail.view(np.uint32), O.counter_mc(op)["final"].view(np.uint32))
+
+
+def test_distribution_matches_reference_cpu_engine(eng, oracle, table):
+    """Distribution-level parity with the reference CPU algorithm (engine R: mt19937 +
+    Lemire + update_fund, src/simulations.cpp:240-252).  Different generators, same law:
+    compare log-return moments within 5 standard errors."""
+    from stock_market_monte_carlo_amd import Engine, MODE_TABLE
+    n, p = 200_000, 360
+    ref, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, 424242)
+    got = eng.simulate(Engine.make_sim(n, p, MODE_TABLE, 777)).final.cpu().numpy()
+    lr, lg = np.log(ref.astype(np.float64)), np.log(got.astype(np.float64))
+    se = np.sqrt(lr.var() / n + lg.var() / n)
+    assert abs(lr.mean() - lg.mean()) < 5 * se
+    assert abs(lr.std() - lg.std()) < 5 * lr.std() / np.sqrt(2 * n) * np.sqrt(2) * 1.5
+    for q in (0.01, 0.25, 0.5, 0.75, 0.99):
+        a, b = np.quantile(lr, q), np.quantile(lg, q)
+        assert abs(a - b) < 0.03, (q, a, b)
+
+
+def test_reference_named_api(table):
+    """The reference's function names and error behaviour (simulations.h)."""
+    import stock_market_monte_carlo_amd as S
+    tot = S.mc_simulations_gpu(10000, 36, 1000.0, table, n_gpus=1, seed=5)
+    assert tot.shape == (10000,) and tot.dtype == np.float32
+    again = S.mc_simulations_gpu(10000, 36, 1000.0, table, n_gpus=1, seed=5)
+    assert np.array_equal(tot.view(np.uint32), again.view(np.uint32))
+    pre = np.full(10000, 1000.0, dtype=np.float32)  # caller pre-sizes (benchmark_mc_cpu_v2.cpp:26)
+    ret = S.mc_simulations(10000, 36, 1000.0, table, final_values=pre, seed=5)
+    assert np.array_equal(pre.view(np.uint32), tot.view(np.uint32)) and ret.base is pre or ret is pre
+    means, variances = S.mc_simulations_gpu_reduceBlock(10000, 36, 1000.0, table, n_gpus=1, seed=5)
+    assert means.shape == variances.shape == (40,)  # ceil(10000 / 256), src/simulations.cu:429-432
+    np.testing.assert_allclose(means[0], tot[:256].astype(np.float64).mean(), rtol=1e-6)
+    with pytest.raises(ValueError):  # src/simulations.cu:693
+        S.mc_simulations_gpu_reduceBlock(1000, 36, 1000.0, table, n_gpus=2)
+    data, fin = S.mc_simulations_keepdata(500, 36, 1000.0, table, seed=5)
+    assert data.shape == (500, 37) and np.array_equal(data[:, -1], fin) and np.all(data[:, 0] == 1000.0)
+    assert np.array_equal(fin.view(np.uint32), tot[:500].view(np.uint32))
+
+
+def test_bad_arguments_are_errors_not_crashes(eng):
+    from stock_market_monte_carlo_amd import Engine, MODE_TABLE, SmmcError
+    with pytest.raises(SmmcError):
+        eng.simulate(Engine.make_sim(10, 10, 7, 1))  # unknown mode
+    with pytest.raises(SmmcError):
+        eng.simulate(Engine.make_sim(10, 10, MODE_TABLE, 1, n_bins=5000), want_stats=True)
+    with pytest.raises(SmmcError):
+        eng.simulate(Engine.make_sim(10, 10, MODE_TABLE, 1, n_bins=10, hist_lo=5, hist_hi=5), want_stats=True)
+    with pytest.raises(SmmcError):
+        eng.set_table(np.zeros(0, dtype=np.float32))
+    with pytest.raises(SmmcError):
+        eng.set_table(np.zeros(20000, dtype=np.float32))

@@ -1,0 +1,108 @@
+// ubench.hip -- instruction issue-rate probes for gfx950 (development tool, not product).
+// Measures wave64 VALU throughput per CU for the instructions the paths kernel leans on.
+// Build: hipcc -O3 --offload-arch=gfx950 tools/ubench.hip -o gpurun_out/ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+constexpr int kIters = 4096;
+constexpr int kUnroll = 16;
+
+template <int OP>
+__global__ __launch_bounds__(256) void probe(unsigned *out, unsigned seed) {
+  unsigned a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9E3779B9u, c = a + 12345u, d = b + 777u;
+  unsigned long long w0 = a, w1 = b, w2 = c, w3 = d;
+  float f0 = a * 1e-9f + 1.0f, f1 = 1.0001f, f2 = 0.5f, f3 = 1.5f;
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int u = 0; u < kUnroll / 4; ++u) {
+      if constexpr (OP == 0) {  // v_xor_b32 (4 independent chains)
+        asm volatile("v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));
+      } else if constexpr (OP == 1) {  // v_mul_lo_u32
+        asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));
+      } else if constexpr (OP == 2) {  // v_mul_hi_u32
+        asm volatile("v_mul_hi_u32 %0, %0, %4\n v_mul_hi_u32 %1, %1, %4\n v_mul_hi_u32 %2, %2, %4\n v_mul_hi_u32 %3, %3, %4"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));
+      } else if constexpr (OP == 3) {  // v_mad_u64_u32
+        asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, 0\n v_mad_u64_u32 %1, vcc, %6, %5, 0\n"
+                     " v_mad_u64_u32 %2, vcc, %7, %5, 0\n v_mad_u64_u32 %3, vcc, %8, %5, 0"
+                     : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(a), "v"(seed), "v"(b), "v"(c), "v"(d) : "vcc");
+        a ^= (unsigned)w0; b ^= (unsigned)w1;  // keep live (2 extra xor per 4 mads)
+      } else if constexpr (OP == 4) {  // v_fma_f32
+        asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5"
+                     : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(1.0000001f), "v"(1e-9f));
+      } else if constexpr (OP == 5) {  // v_mul_u32_u24
+        asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %4"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));
+      } else if constexpr (OP == 6) {  // v_mul_hi_u32_u24
+        asm volatile("v_mul_hi_u32_u24 %0, %0, %4\n v_mul_hi_u32_u24 %1, %1, %4\n v_mul_hi_u32_u24 %2, %2, %4\n v_mul_hi_u32_u24 %3, %3, %4"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));
+      } else if constexpr (OP == 7) {  // v_sqrt_f32
+        asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3"
+                     : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));
+      } else if constexpr (OP == 8) {  // v_cvt_f32_u32
+        asm volatile("v_cvt_f32_u32 %0, %4\n v_cvt_f32_u32 %1, %5\n v_cvt_f32_u32 %2, %6\n v_cvt_f32_u32 %3, %7"
+                     : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(a), "v"(b), "v"(c), "v"(d));
+      } else if constexpr (OP == 9) {  // v_pk_fma_f32 (2 fma per lane per instruction)
+        asm volatile("v_pk_fma_f32 %0, %0, %2, %3\n v_pk_fma_f32 %1, %1, %2, %3\n v_pk_fma_f32 %0, %0, %2, %3\n v_pk_fma_f32 %1, %1, %2, %3"
+                     : "+v"(w0), "+v"(w1) : "v"(w2), "v"(w3));
+      } else if constexpr (OP == 10) {  // v_mul_f32 + v_fmac x2 dependent chain (the div100 step)
+        asm volatile("v_mul_f32 %1, 0x3c23d70a, %0\n v_fmac_f32 %0, 0xc2c80000, %1\n v_fmac_f32 %1, 0x3c23d70a, %0\n v_mul_f32 %0, %1, %2"
+                     : "+v"(f0), "+v"(f1) : "v"(f2));
+      }
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ (unsigned)w0 ^ (unsigned)w1 ^ (unsigned)w2 ^ (unsigned)w3 ^
+                                               __float_as_uint(f0 + f1 + f2 + f3);
+}
+
+template <int OP>
+int run(const char *name, int waves_per_simd, unsigned *d_out, int cus) {
+  // blocks of 256 threads = 4 waves = 1 wave per SIMD; `waves_per_simd` blocks per CU
+  int grid = cus * waves_per_simd;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(probe<OP>, dim3(grid), dim3(256), 0, 0, d_out, 1u);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(probe<OP>, dim3(grid), dim3(256), 0, 0, d_out, 2u);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  double insts_per_wave = (double)kIters * kUnroll;  // target instructions per wave
+  double waves = (double)grid * 4;
+  double total = insts_per_wave * waves;
+  double per_simd_per_s = total / (ms * 1e-3) / (cus * 4.0);
+  printf("%-22s waves/SIMD=%d  %8.3f ms  %7.2f Ginst/s/SIMD  => %5.2f clk/inst @2.4GHz\n", name, waves_per_simd, ms,
+         per_simd_per_s * 1e-9, 2.4e9 / per_simd_per_s);
+  return 0;
+}
+
+int main() {
+  hipDeviceProp_t p;
+  CK(hipGetDeviceProperties(&p, 0));
+  int cus = p.multiProcessorCount;
+  printf("%s CUs=%d clock=%d kHz\n", p.gcnArchName, cus, p.clockRate);
+  unsigned *d_out;
+  CK(hipMalloc(&d_out, sizeof(unsigned) * cus * 8 * 256));
+  for (int w : {1, 2, 4, 8}) {
+    run<0>("v_xor_b32", w, d_out, cus);
+    run<1>("v_mul_lo_u32", w, d_out, cus);
+    run<2>("v_mul_hi_u32", w, d_out, cus);
+    run<3>("v_mad_u64_u32(+.5xor)", w, d_out, cus);
+    run<4>("v_fma_f32", w, d_out, cus);
+    run<5>("v_mul_u32_u24", w, d_out, cus);
+    run<6>("v_mul_hi_u32_u24", w, d_out, cus);
+    run<7>("v_sqrt_f32", w, d_out, cus);
+    run<8>("v_cvt_f32_u32", w, d_out, cus);
+    run<9>("v_pk_fma_f32", w, d_out, cus);
+    run<10>("div100 chain(4 inst)", w, d_out, cus);
+  }
+  return 0;
+}
