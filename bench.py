@@ -52,6 +52,32 @@ def load_table():
     return np.array(vals, dtype=np.float32)
 
 
+def usable_cores():
+    """CPU cores this process can really use: affinity mask capped by the cgroup CPU quota."""
+    if os.environ.get("SMMC_CPU_CORES"):
+        return max(1, int(os.environ["SMMC_CPU_CORES"]))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 2
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        cores = min(cores, max(1, int(quota + 0.5)))
+    return cores
+
+
 def cpu_baseline(table, budget_s=15.0):
     """Times the oracle's reference-faithful engine (R) -- the checker, used here only as
     the CPU baseline the metric asks for."""
@@ -59,11 +85,7 @@ def cpu_baseline(table, budget_s=15.0):
     O.build()
     # the reference uses hardware_concurrency() - 1 threads (src/simulations.cpp:218-219);
     # count the cores this process may actually run on, not the host's
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 2
-    threads = max(1, cores - 1)
+    threads = max(1, usable_cores() - 1)
     n, dt, used = 50_000, 0.0, threads
     while True:  # grow the sample until it is >= 2/3 of the budget of CPU wall time
         t0 = time.perf_counter()

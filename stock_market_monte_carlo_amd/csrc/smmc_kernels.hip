@@ -24,17 +24,23 @@ constexpr uint32_t kPhiloxM1 = 0xCD9E8D57u;
 constexpr uint32_t kWeyl0 = 0x9E3779B9u;
 constexpr uint32_t kWeyl1 = 0xBB67AE85u;
 
+// a ^ b ^ c in one VALU instruction (gfx950 v_bitop3_b32, truth table 0x96); hipcc
+// does not form it from two chained XORs on its own.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
 // Philox4x32-10 (Salmon et al., SC'11).  The key schedule is wave-uniform and
-// lives in SGPRs; per round the lanes pay two 32x32->64 multiplies and two
-// three-input XORs.
+// lives in SGPRs; per round the lanes pay two 32x32->64 multiplies
+// (v_mad_u64_u32) and two three-input XORs (v_bitop3_b32).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = static_cast<uint64_t>(kPhiloxM0) * c0;
     const uint64_t p1 = static_cast<uint64_t>(kPhiloxM1) * c2;
-    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = xor3(static_cast<uint32_t>(p1 >> 32), c1, k0);
+    const uint32_t n2 = xor3(static_cast<uint32_t>(p0 >> 32), c3, k1);
     c1 = static_cast<uint32_t>(p1);
     c3 = static_cast<uint32_t>(p0);
     c0 = n0;
@@ -72,6 +78,21 @@ __device__ __forceinline__ float compound(float total, float a) {
   return div100<kExactDiv>(m);
 }
 
+// sqrt(x) correctly rounded, for x = +0 or x in [2^-40, 64] (no input scaling, no
+// inf/NaN handling: the Box-Muller argument is 0 or lies in [1.19e-7, 45.8]).  v_sqrt_f32 is within
+// 1 ulp; the two FMA residuals pick the neighbour when it is the better rounding.
+// Bit-identical to the IEEE sqrtf on that domain (device self-test: smmc_selftest).
+__device__ __forceinline__ float sqrt_rn_pos(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+  const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float r_dn = __builtin_fmaf(-s_dn, s, x);
+  const float r_up = __builtin_fmaf(-s_up, s, x);
+  s = (r_dn <= 0.0f) ? s_dn : s;
+  s = (r_up > 0.0f) ? s_up : s;
+  return s;
+}
+
 // ln(x), x a normal positive binary32: Cephes-style degree-8 kernel on
 // [sqrt(1/2), sqrt(2)).  Same operation sequence as the oracle's log kernel.
 __device__ __forceinline__ float log_kernel(float x) {
@@ -104,7 +125,7 @@ __device__ __forceinline__ float log_kernel(float x) {
 __device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float &z_cos, float &z_sin) {
   const float u1 = __builtin_fmaf(static_cast<float>(ua), 0x1p-32f, 0x1p-33f);  // (0, 1]
   const float t = -2.0f * log_kernel(u1);
-  const float r = __builtin_sqrtf(t);  // IEEE sqrt (correctly rounded)
+  const float r = sqrt_rn_pos(t);  // == IEEE sqrtf(t) on [0, 46]
 
   const uint32_t v = ub + 0x20000000u;
   const int32_t g = static_cast<int32_t>(v & 0x3fffffffu) - 0x20000000;
@@ -441,7 +462,34 @@ __global__ __launch_bounds__(kBlock) void keepdata_kernel(const KernelArgs k) {
   }
 }
 
+// Device self-test of the two arithmetic shortcuts against the compiler's IEEE forms,
+// over the binary32 patterns [lo, hi): counts[0] += mismatches of div100<false> vs
+// x / 100.0f, counts[1] += mismatches of sqrt_rn_pos vs sqrtf.
+__global__ __launch_bounds__(kBlock) void selftest_kernel(uint32_t lo, uint32_t hi,
+                                                          unsigned long long *counts) {
+  unsigned long long bad_div = 0, bad_sqrt = 0;
+  const uint64_t n = static_cast<uint64_t>(hi) - lo;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * kBlock) {
+    const float x = __uint_as_float(lo + static_cast<uint32_t>(i));
+    if (__float_as_uint(div100<false>(x)) != __float_as_uint(x / 100.0f)) ++bad_div;
+    if (__float_as_uint(sqrt_rn_pos(x)) != __float_as_uint(__builtin_sqrtf(x))) ++bad_sqrt;
+  }
+  bad_div = wave_sum(bad_div);
+  bad_sqrt = wave_sum(bad_sqrt);
+  if ((threadIdx.x & 63) == 0) {
+    if (bad_div) atomicAdd(&counts[0], bad_div);
+    if (bad_sqrt) atomicAdd(&counts[1], bad_sqrt);
+  }
+}
+
 }  // namespace
+
+hipError_t launch_selftest(uint32_t lo, uint32_t hi, unsigned long long *d_counts, uint32_t grid,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(selftest_kernel, dim3(grid), dim3(kBlock), 0, stream, lo, hi, d_counts);
+  return hipGetLastError();
+}
 
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins) {
   return (static_cast<size_t>(table_len) + n_bins) * 4u;
