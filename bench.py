@@ -117,6 +117,7 @@ def main():
     import torch
     import torch.distributed as dist
     import stock_market_monte_carlo_amd as S
+    from stock_market_monte_carlo_amd.dist import gather_stats_records
     from stock_market_monte_carlo_amd.engine import merge_stats_bytes, stats_from_bytes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,13 +141,15 @@ def main():
     want_chunks = args.outputs == "all"
     want_stats = args.outputs in ("all", "stats")
     final = torch.empty(n, dtype=torch.float32, device=eng.tdevice) if want_final else None
-    rec_bytes = 64 + 8 * 100
-    gathered = torch.empty(world * rec_bytes, dtype=torch.uint8, device=eng.tdevice) if world > 1 else None
+    records = None
 
     def step():
+        # the whole per-step job: simulate this rank's shard, then (N > 1) the one RCCL
+        # all_gather of the statistics records, merged in rank order on the host
+        nonlocal records
         r = eng.simulate(sim, want_final=want_final, want_chunk_stats=want_chunks, want_stats=want_stats, out=final)
-        if world > 1 and want_stats:
-            dist.all_gather_into_tensor(gathered, r.stats_raw)
+        if want_stats:
+            records = gather_stats_records(r.stats_raw) if world > 1 else None
         return r
 
     def barrier():
@@ -174,8 +177,7 @@ def main():
     stats = None
     if want_stats:
         if world > 1:
-            raw = gathered.cpu().numpy().tobytes()
-            stats = stats_from_bytes(merge_stats_bytes([raw[i * rec_bytes:(i + 1) * rec_bytes] for i in range(world)]))
+            stats = stats_from_bytes(merge_stats_bytes(records))
         else:
             stats = eng.read_stats(last.stats_raw)
         assert stats.count == n * world, (stats.count, n * world)

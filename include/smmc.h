@@ -149,15 +149,27 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
 /* Blocks until everything enqueued on the engine stream has finished. */
 int smmc_engine_sync(smmc_engine *e);
 
-/* Simulates into HOST memory: final values of all paths are produced in chunks
- * and copied back on a side stream while the next chunk computes (the async
+/* Simulates into HOST memory: outputs are produced in chunks of 2^24 paths and
+ * copied back on a side stream while the next chunk computes (the async
  * cudaMemcpy pattern of mc_simulations_multi_gpu_launcher_async,
  * src/simulations.cu:615-626, without its extra host copy :643-644).
- * host_final: n_paths floats (pinned or pageable).  progress, if not NULL, is set
- * to the number of finished paths after every chunk (the n_simulations counter
- * of src/simulations.cpp:254).  stats/hist (host) may be NULL.  Synchronous. */
+ * Host pointers (pinned or pageable), any may be NULL:
+ *   host_final       n_paths floats
+ *   host_chunk_mean  ceil(n_paths / SMMC_CHUNK) floats  (means of the reduceBlock API)
+ *   host_chunk_var   same length                         (variances)
+ *   progress         set to the number of finished paths after every chunk (the
+ *                    n_simulations counter of src/simulations.cpp:254)
+ *   stats, hist      merged statistics header and n_bins bucket counts
+ * Synchronous. */
 int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *host_final,
-                                 volatile int64_t *progress, smmc_stats *stats, uint64_t *hist);
+                                 float *host_chunk_mean, float *host_chunk_var, volatile int64_t *progress,
+                                 smmc_stats *stats, uint64_t *hist);
+
+/* keepdata into HOST memory: host_traj is n_paths x (n_periods + 1) floats path-major,
+ * host_final (may be NULL) n_paths floats.  Produced in device-sized slices.
+ * Synchronous.  mc_simulations_keepdata, src/simulations.cpp:139-202. */
+int smmc_engine_simulate_keepdata_to_host(smmc_engine *e, const smmc_sim *sim, float *host_traj,
+                                          float *host_final);
 
 /* Device-time instrumentation: when enabled, every simulate call brackets its
  * main kernel with HIP events on the engine stream.  smmc_engine_kernel_ms

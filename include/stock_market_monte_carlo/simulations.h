@@ -1,0 +1,92 @@
+// simulations.h -- C++ drop-in for the Monte-Carlo part of the reference's public
+// header (include/stock_market_monte_carlo/simulations.h of
+// matthijsvk/stock_market_monte_carlo), backed by libsmmc_hip.so on an MI355X.
+//
+// Every function below keeps the reference's name, parameter list and ownership
+// rules, so the reference's own callers (examples/benchmark_mc_*.cpp,
+// examples/visualize_returns_*.cpp) compile against this header unchanged.  The
+// reference location of each one is cited.  What is NOT here: the CSV-dumping demos
+// (one_simulation_*, monte_carlo_*), which are file I/O, not the hot path.
+//
+// Self-contained on purpose: the reference header relies on fmt's transitive
+// includes for <atomic> and <string>.
+#ifndef SMMC_DROPIN_SIMULATIONS_H
+#define SMMC_DROPIN_SIMULATIONS_H
+
+#include <atomic>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+// ---- compounding core (src/simulations.cpp:14-39) ------------------------------------
+float update_fund(float fund_value, float period_return);                             // :14-16
+void __many_updates(float *returns, float *totals, unsigned int n_periods);           // :18-22
+// :24-39 -- returns n_periods + 1 values, [0] == fund_value
+std::vector<float> many_updates(float fund_value, std::vector<float> &returns, unsigned int n_periods);
+// the overload the reference header declares (simulations.h:11-13) but never defines
+std::vector<float> many_updates(float fund_value, std::vector<float> &returns, long n_updates);
+
+// ---- returns sources (src/simulations.cpp:41-55, 83-112) ------------------------------
+std::vector<float> sample_returns_gaussian(unsigned int n, float return_mean, float return_std);   // :41-55
+std::vector<float> read_historical_returns(std::string csv_fpath);                                  // :83-93
+std::vector<float> sample_returns_historical(unsigned int n, std::vector<float> &historical_returns);  // :95-112
+
+// ---- "CPU" engines of the reference, here executed on the GPU -------------------------
+// src/simulations.cpp:204-266.  final_values must already hold max_n_simulations
+// entries (the reference writes by index, :252); n_simulations advances while it runs.
+void mc_simulations(std::atomic<long> &n_simulations, long max_n_simulations, unsigned int n_periods,
+                    float initial_capital, std::vector<float> &historical_returns,
+                    std::vector<float> &final_values);
+// src/simulations.cpp:139-202.  mc_data and final_values must hold max_n_simulations
+// entries; mc_data[i] becomes the n_periods + 1 values of path i.
+void mc_simulations_keepdata(std::atomic<long> &n_simulations, long max_n_simulations, unsigned int n_periods,
+                             float initial_capital, std::vector<float> &historical_returns,
+                             std::vector<std::vector<float>> &mc_data, std::vector<float> &final_values);
+
+// ---- GPU engines (src/simulations.cu:661-697) ------------------------------------------
+// totals is replaced by a vector of max_n_simulations final values (:643-644).
+void mc_simulations_gpu(std::atomic<long> &n_simulations, long max_n_simulations, int n_periods,
+                        float initial_capital, std::vector<float> &returns, std::vector<float> &totals,
+                        int n_gpus);
+// means / variances are resized to ceil(max_n_simulations / 256) (:429-432); throws
+// std::invalid_argument unless n_gpus == 1 (:693).
+void mc_simulations_gpu_reduceBlock(std::atomic<long> &n_simulations, long max_n_simulations, int n_periods,
+                                    float initial_capital, std::vector<float> &returns,
+                                    std::vector<float> &means, std::vector<float> &variances, int n_gpus);
+
+// ---- additions (not in the reference) ---------------------------------------------------
+namespace smmc {
+
+// The reference has no seed (std::random_device per path).  The drop-in draws one
+// 64-bit seed per call from std::random_device unless a seed is fixed here or through
+// the environment variable SMMC_SEED.  fix_seed(false, ...) returns to random seeds.
+void fix_seed(bool fixed, std::uint64_t seed);
+
+// Gaussian-returns variant of mc_simulations_gpu (mean / std in percent per period,
+// examples/monte_carlo_simulated.cpp:11-12): the mode BASELINE configs 2, 4 and 5 name.
+void mc_simulations_gpu_gaussian(std::atomic<long> &n_simulations, long max_n_simulations, int n_periods,
+                                 float initial_capital, float return_mean, float return_std,
+                                 std::vector<float> &totals, int n_gpus);
+
+// Fused statistics of a run, replacing the host passes of examples/benchmark_mc_gpu.cpp:7-41.
+struct Summary {
+  std::uint64_t count = 0, below = 0, underflow = 0, overflow = 0;
+  double sum = 0, sumsq = 0;
+  float min = 0, max = 0;
+  std::vector<std::uint64_t> hist;
+  double mean() const { return count ? sum / double(count) : 0.0; }
+  double stddev() const;  // population
+};
+// Runs the simulation WITHOUT materialising final values on the host: only the
+// statistics record crosses PCIe.  gaussian == false draws from `returns`.
+Summary mc_summary(long max_n_simulations, int n_periods, float initial_capital, bool gaussian,
+                   std::vector<float> &returns, float return_mean, float return_std, float below_threshold,
+                   unsigned n_bins, float hist_lo, float hist_hi, int n_gpus);
+
+// The 1127-entry synthetic returns table bundled with the library (percent units),
+// used by the CLIs when data/SP500_monthly_returns.csv is absent.
+std::vector<float> bundled_synthetic_returns();
+
+}  // namespace smmc
+
+#endif

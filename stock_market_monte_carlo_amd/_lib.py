@@ -69,7 +69,8 @@ SYMBOLS = [
     ("smmc_engine_simulate_keepdata", C.c_int, [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p]),
     ("smmc_engine_sync", C.c_int, [C.c_void_p]),
     ("smmc_engine_simulate_to_host", C.c_int,
-     [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+     [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    ("smmc_engine_simulate_keepdata_to_host", C.c_int, [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p]),
     ("smmc_engine_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("smmc_engine_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     ("smmc_engine_selftest", C.c_int,

@@ -80,6 +80,8 @@ struct smmc_engine {
   // simulate_to_host staging
   float *d_stage[2] = {nullptr, nullptr};
   uint64_t stage_paths = 0;
+  float *d_stage_cs[2] = {nullptr, nullptr};  // chunk means then variances
+  uint64_t stage_cs = 0;
   void *d_stage_stats = nullptr;
   size_t stage_stats_bytes = 0;
   hipEvent_t ev_compute[2] = {nullptr, nullptr};
@@ -303,6 +305,7 @@ void smmc_engine_destroy(smmc_engine *e) {
     if (e->ev_compute[i]) (void)hipEventDestroy(e->ev_compute[i]);
     if (e->ev_copy[i]) (void)hipEventDestroy(e->ev_copy[i]);
     if (e->d_stage[i]) (void)hipFree(e->d_stage[i]);
+    if (e->d_stage_cs[i]) (void)hipFree(e->d_stage_cs[i]);
   }
   if (e->d_stage_stats) (void)hipFree(e->d_stage_stats);
   if (e->d_table) (void)hipFree(e->d_table);
@@ -382,16 +385,19 @@ int smmc_engine_sync(smmc_engine *e) {
 }
 
 int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *host_final,
-                                 volatile int64_t *progress, smmc_stats *stats, uint64_t *hist) {
+                                 float *host_chunk_mean, float *host_chunk_var, volatile int64_t *progress,
+                                 smmc_stats *stats, uint64_t *hist) {
   int rc = check_sim(e, sim);
   if (rc) return rc;
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
   const uint64_t n = sim->n_paths;
-  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), kHostChunkPaths);
+  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), kHostChunkPaths);  // multiple of 256 when n > chunk
   const uint64_t n_chunks = (n + chunk - 1) / chunk;
   const bool want_stats = stats != nullptr || hist != nullptr;
+  const bool want_cs = host_chunk_mean != nullptr || host_chunk_var != nullptr;
   const size_t rec = smmc_stats_bytes(sim->n_bins);
+  const uint64_t cs_per_chunk = (chunk + smmc::kBlock - 1) / smmc::kBlock;
 
   if (!e->copy_stream) SMMC_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
   for (int i = 0; i < 2; ++i) {
@@ -407,6 +413,16 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
     for (int i = 0; i < 2; ++i) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_stage[i]), sizeof(float) * chunk));
     e->stage_paths = chunk;
   }
+  if (want_cs && e->stage_cs < cs_per_chunk) {
+    for (int i = 0; i < 2; ++i) {
+      if (e->d_stage_cs[i]) SMMC_HIP(hipFree(e->d_stage_cs[i]));
+      e->d_stage_cs[i] = nullptr;
+    }
+    e->stage_cs = 0;
+    for (int i = 0; i < 2; ++i)
+      SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_stage_cs[i]), sizeof(float) * 2 * cs_per_chunk));
+    e->stage_cs = cs_per_chunk;
+  }
   if (want_stats && e->stage_stats_bytes < rec * std::max<uint64_t>(n_chunks, 1)) {
     if (e->d_stage_stats) SMMC_HIP(hipFree(e->d_stage_stats));
     e->d_stage_stats = nullptr;
@@ -416,22 +432,33 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
   }
   if (progress) *progress = 0;
 
-  // Pipeline: the kernel of chunk c (engine stream) overlaps the D2H copy of chunk
-  // c - 1 (copy stream).  Buffer b = c & 1 is reused once its copy has finished.
+  // Pipeline: the kernel of chunk c (engine stream) overlaps the D2H copies of chunk
+  // c - 1 (copy stream).  Buffer b = c & 1 is reused once its copies have finished.
+  const bool copies = host_final || want_cs;
   for (uint64_t c = 0; c < n_chunks; ++c) {
     const int b = static_cast<int>(c & 1);
     smmc_sim part = *sim;
     part.first_path = sim->first_path + c * chunk;
     part.n_paths = std::min<uint64_t>(chunk, n - c * chunk);
-    if (c >= 2) SMMC_HIP(hipStreamWaitEvent(e->stream, e->ev_copy[b], 0));
+    const uint64_t cs_here = (part.n_paths + smmc::kBlock - 1) / smmc::kBlock;
+    if (c >= 2 && copies) SMMC_HIP(hipStreamWaitEvent(e->stream, e->ev_copy[b], 0));
     void *d_rec = want_stats ? static_cast<char *>(e->d_stage_stats) + rec * c : nullptr;
-    rc = enqueue_simulation(e, &part, host_final ? e->d_stage[b] : nullptr, nullptr, nullptr, d_rec);
+    float *d_cm = want_cs ? e->d_stage_cs[b] : nullptr;
+    float *d_cv = want_cs ? e->d_stage_cs[b] + cs_per_chunk : nullptr;
+    rc = enqueue_simulation(e, &part, host_final ? e->d_stage[b] : nullptr, d_cm, d_cv, d_rec);
     if (rc) return rc;
-    if (host_final) {
+    if (copies) {
       SMMC_HIP(hipEventRecord(e->ev_compute[b], e->stream));
       SMMC_HIP(hipStreamWaitEvent(e->copy_stream, e->ev_compute[b], 0));
-      SMMC_HIP(hipMemcpyAsync(host_final + c * chunk, e->d_stage[b], sizeof(float) * part.n_paths,
-                              hipMemcpyDeviceToHost, e->copy_stream));
+      if (host_final)
+        SMMC_HIP(hipMemcpyAsync(host_final + c * chunk, e->d_stage[b], sizeof(float) * part.n_paths,
+                                hipMemcpyDeviceToHost, e->copy_stream));
+      if (host_chunk_mean)
+        SMMC_HIP(hipMemcpyAsync(host_chunk_mean + c * cs_per_chunk, d_cm, sizeof(float) * cs_here,
+                                hipMemcpyDeviceToHost, e->copy_stream));
+      if (host_chunk_var)
+        SMMC_HIP(hipMemcpyAsync(host_chunk_var + c * cs_per_chunk, d_cv, sizeof(float) * cs_here,
+                                hipMemcpyDeviceToHost, e->copy_stream));
       SMMC_HIP(hipEventRecord(e->ev_copy[b], e->copy_stream));
       if (progress && c >= 1) {
         SMMC_HIP(hipEventSynchronize(e->ev_copy[b ^ 1]));
@@ -440,7 +467,7 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
     }
   }
   SMMC_HIP(hipStreamSynchronize(e->stream));
-  if (host_final) SMMC_HIP(hipStreamSynchronize(e->copy_stream));
+  if (copies) SMMC_HIP(hipStreamSynchronize(e->copy_stream));
   if (progress) *progress = static_cast<int64_t>(n);
 
   if (want_stats) {
@@ -460,6 +487,38 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
     if (stats) *stats = *h;
     if (hist && sim->n_bins) std::memcpy(hist, acc.data() + sizeof(smmc_stats), sizeof(uint64_t) * sim->n_bins);
   }
+  return SMMC_OK;
+}
+
+int smmc_engine_simulate_keepdata_to_host(smmc_engine *e, const smmc_sim *sim, float *host_traj, float *host_final) {
+  int rc = check_sim(e, sim);
+  if (rc) return rc;
+  if (!host_traj) return fail(SMMC_ERR_INVALID, "host_traj is NULL");
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  const uint64_t row = static_cast<uint64_t>(sim->n_periods) + 1;
+  // trajectories of one slice: at most ~1 GiB on the device, a multiple of 256 paths
+  uint64_t slice = std::max<uint64_t>((1ull << 28) / row, 1);
+  slice = std::max<uint64_t>(slice / smmc::kBlock * smmc::kBlock, smmc::kBlock);
+  slice = std::min<uint64_t>(slice, std::max<uint64_t>(sim->n_paths, 1));
+  float *d_traj = nullptr, *d_fin = nullptr;
+  SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&d_traj), sizeof(float) * slice * row));
+  hipError_t err = hipMalloc(reinterpret_cast<void **>(&d_fin), sizeof(float) * slice);
+  for (uint64_t first = 0; err == hipSuccess && first < sim->n_paths; first += slice) {
+    smmc_sim part = *sim;
+    part.first_path = sim->first_path + first;
+    part.n_paths = std::min<uint64_t>(slice, sim->n_paths - first);
+    rc = smmc_engine_simulate_keepdata(e, &part, d_traj, d_fin);
+    if (rc) break;
+    err = hipMemcpyAsync(host_traj + first * row, d_traj, sizeof(float) * part.n_paths * row, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess && host_final)
+      err = hipMemcpyAsync(host_final + first, d_fin, sizeof(float) * part.n_paths, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  }
+  (void)hipFree(d_traj);
+  if (d_fin) (void)hipFree(d_fin);
+  if (rc) return rc;
+  if (err != hipSuccess) return fail(SMMC_ERR_HIP, "keepdata_to_host failed: %s", hipGetErrorString(err));
   return SMMC_OK;
 }
 

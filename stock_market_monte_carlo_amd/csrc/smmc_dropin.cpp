@@ -1,0 +1,375 @@
+// smmc_dropin.cpp -- the reference's C++ free functions (declared in
+// include/stock_market_monte_carlo/simulations.h) implemented over the C ABI.
+//
+// Host-side counterpart of the parts of src/simulations.cpp and the wrappers at
+// src/simulations.cu:661-697 that callers link against.  No HIP types appear here:
+// everything device-side goes through smmc.h.
+#include "stock_market_monte_carlo/simulations.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <thread>
+
+#include "smmc.h"
+
+namespace {
+
+static_assert(sizeof(std::atomic<long>) == sizeof(int64_t) && std::atomic<long>::is_always_lock_free,
+              "the progress counter is updated through a plain 64-bit store");
+
+[[noreturn]] void raise(int rc) {
+  std::string msg = std::string("smmc: ") + smmc_last_error();
+  if (rc == SMMC_ERR_INVALID) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+void check(int rc) {
+  if (rc != SMMC_OK) raise(rc);
+}
+
+// One engine per device for the process; an engine is not re-entrant, so calls on the
+// same device serialise on its mutex (calls on different devices run concurrently).
+struct Slot {
+  std::mutex busy;
+  smmc_engine *engine = nullptr;
+  ~Slot() {
+    if (engine) smmc_engine_destroy(engine);
+  }
+};
+std::mutex g_slots_mutex;
+std::map<int, std::unique_ptr<Slot>> g_slots;
+
+Slot &slot_for(int device) {
+  std::lock_guard<std::mutex> lock(g_slots_mutex);
+  auto &s = g_slots[device];
+  if (!s) s.reset(new Slot());
+  return *s;
+}
+
+std::mutex g_seed_mutex;
+bool g_seed_fixed = false;
+std::uint64_t g_seed = 0;
+
+std::uint64_t next_seed() {
+  {
+    std::lock_guard<std::mutex> lock(g_seed_mutex);
+    if (g_seed_fixed) return g_seed;
+  }
+  if (const char *env = std::getenv("SMMC_SEED")) return std::strtoull(env, nullptr, 0);
+  std::random_device rd;  // the reference's entropy source, src/simulations.cpp:245
+  return (static_cast<std::uint64_t>(rd()) << 32) ^ rd();
+}
+
+smmc_sim make_sim(int mode, std::uint64_t seed, std::uint64_t first, std::uint64_t n, unsigned periods, float capital) {
+  smmc_sim s{};
+  s.struct_size = sizeof(smmc_sim);
+  s.mode = mode;
+  s.seed = seed;
+  s.first_path = first;
+  s.n_paths = n;
+  s.n_periods = periods;
+  s.initial_capital = capital;
+  s.gauss_mean = 0.5f;
+  s.gauss_std = 0.83333f;
+  s.below_threshold = capital;
+  return s;
+}
+
+int visible_devices() {
+  int n = 0;
+  check(smmc_device_count(&n));
+  return n;
+}
+
+// Runs `work(device, first_path, count)` for each of n_gpus contiguous shards, one host
+// thread per device.  Shard g covers floor(N/G) paths plus one of the N mod G leftovers
+// (the reference drops the remainder, src/simulations.cu:602-603).
+template <typename Work>
+void for_each_shard(long n_total, int n_gpus, Work work) {
+  if (n_gpus < 1) throw std::invalid_argument("smmc: n_gpus must be >= 1");
+  const int have = visible_devices();
+  if (have == 0) throw std::runtime_error("smmc: no MI355X visible; this library has no CPU fallback");
+  if (n_gpus > have) throw std::invalid_argument("smmc: n_gpus exceeds the visible devices");
+  const std::uint64_t n = static_cast<std::uint64_t>(n_total);
+  const std::uint64_t base = n / n_gpus, extra = n % n_gpus;
+  std::vector<std::thread> threads;
+  std::vector<std::string> errors(n_gpus);
+  std::uint64_t first = 0;
+  for (int g = 0; g < n_gpus; ++g) {
+    const std::uint64_t count = base + (static_cast<std::uint64_t>(g) < extra ? 1 : 0);
+    auto body = [&, g, first, count]() {
+      try {
+        work(g, first, count);
+      } catch (const std::exception &ex) {
+        errors[g] = ex.what();
+      }
+    };
+    if (n_gpus == 1) body(); else threads.emplace_back(body);
+    first += count;
+  }
+  for (auto &t : threads) t.join();
+  for (const auto &e : errors)
+    if (!e.empty()) throw std::runtime_error(e);
+}
+
+// Engine of `device` with `table` loaded (table may be null for Gaussian runs).
+struct Session {
+  std::unique_lock<std::mutex> lock;
+  smmc_engine *engine;
+  Session(int device, const std::vector<float> *table) : lock(slot_for(device).busy) {
+    Slot &s = slot_for(device);
+    if (!s.engine) check(smmc_engine_create(device, SMMC_STREAM_NEW, &s.engine));
+    engine = s.engine;
+    if (table) {
+      if (table->empty()) throw std::invalid_argument("smmc: empty returns table");
+      check(smmc_engine_set_table(engine, table->data(), static_cast<uint32_t>(table->size())));
+    }
+  }
+};
+
+void run_final_values(std::atomic<long> &n_simulations, long n_total, unsigned periods, float capital, int mode,
+                      const std::vector<float> *table, float mean, float stddev, float *out, int n_gpus) {
+  const std::uint64_t seed = next_seed();
+  n_simulations = 0;
+  if (n_gpus == 1) {
+    Session ses(0, table);
+    smmc_sim sim = make_sim(mode, seed, 0, static_cast<std::uint64_t>(n_total), periods, capital);
+    sim.gauss_mean = mean;
+    sim.gauss_std = stddev;
+    // the engine stores finished-path counts straight into the caller's counter
+    check(smmc_engine_simulate_to_host(ses.engine, &sim, out, nullptr, nullptr,
+                                       reinterpret_cast<volatile int64_t *>(&n_simulations), nullptr, nullptr));
+  } else {
+    for_each_shard(n_total, n_gpus, [&](int dev, std::uint64_t first, std::uint64_t count) {
+      Session ses(dev, table);
+      smmc_sim sim = make_sim(mode, seed, first, count, periods, capital);
+      sim.gauss_mean = mean;
+      sim.gauss_std = stddev;
+      check(smmc_engine_simulate_to_host(ses.engine, &sim, out + first, nullptr, nullptr, nullptr, nullptr, nullptr));
+      n_simulations += static_cast<long>(count);
+    });
+  }
+  n_simulations = n_total;  // src/simulations.cu:678
+}
+
+}  // namespace
+
+// ---- compounding core --------------------------------------------------------------------
+
+float update_fund(float fund_value, float period_return) { return smmc_update_fund(fund_value, period_return); }
+
+void __many_updates(float *returns, float *totals, unsigned int n_periods) {
+  smmc_many_updates(returns, totals, n_periods);
+}
+
+std::vector<float> many_updates(float fund_value, std::vector<float> &returns, unsigned int n_periods) {
+  if (returns.size() < n_periods) throw std::out_of_range("smmc: many_updates needs n_periods returns");
+  std::vector<float> totals(static_cast<size_t>(n_periods) + 1);  // heap, not the reference's VLA (:28)
+  totals[0] = fund_value;
+  smmc_many_updates(returns.data(), totals.data(), n_periods);
+  return totals;
+}
+
+std::vector<float> many_updates(float fund_value, std::vector<float> &returns, long n_updates) {
+  if (n_updates < 0 || n_updates > 0xFFFFFFFFl) throw std::invalid_argument("smmc: n_updates out of range");
+  return many_updates(fund_value, returns, static_cast<unsigned int>(n_updates));
+}
+
+// ---- returns sources -----------------------------------------------------------------------
+
+std::vector<float> sample_returns_gaussian(unsigned int n, float return_mean, float return_std) {
+  // src/simulations.cpp:41-55 (which writes into a reserve()d vector; here it is sized)
+  std::mt19937_64 engine(next_seed());
+  std::normal_distribution<float> dist(return_mean, return_std);
+  std::vector<float> out(n);
+  for (auto &v : out) v = dist(engine);
+  return out;
+}
+
+std::vector<float> sample_returns_historical(unsigned int n, std::vector<float> &historical_returns) {
+  // src/simulations.cpp:95-112
+  if (historical_returns.empty()) throw std::out_of_range("smmc: empty returns table");
+  std::mt19937 engine(static_cast<std::uint32_t>(next_seed()));
+  std::uniform_int_distribution<int> pick(0, static_cast<int>(historical_returns.size()) - 1);
+  std::vector<float> out;
+  out.reserve(n);
+  for (unsigned int i = 0; i < n; ++i) out.push_back(historical_returns.at(pick(engine)));
+  return out;
+}
+
+std::vector<float> read_historical_returns(std::string csv_fpath) {
+  // src/simulations.cpp:83-93: column "returns" of a CSV; other columns ignored.  The file
+  // python/get_data.py:59-69 writes has an empty cell in its first data row: skipped.
+  std::ifstream in(csv_fpath);
+  if (!in) throw std::runtime_error("smmc: cannot open " + csv_fpath);
+  std::string line;
+  if (!std::getline(in, line)) throw std::runtime_error("smmc: " + csv_fpath + " is empty");
+  auto split = [](const std::string &l) {
+    std::vector<std::string> cells;
+    std::string cell;
+    std::stringstream ss(l);
+    while (std::getline(ss, cell, ',')) cells.push_back(cell);
+    if (!l.empty() && l.back() == ',') cells.emplace_back();
+    return cells;
+  };
+  auto trim = [](std::string s) {
+    const char *ws = " \t\r\n\"";
+    const size_t a = s.find_first_not_of(ws);
+    if (a == std::string::npos) return std::string();
+    return s.substr(a, s.find_last_not_of(ws) - a + 1);
+  };
+  int col = -1;
+  const auto header = split(line);
+  for (size_t i = 0; i < header.size(); ++i)
+    if (trim(header[i]) == "returns") col = static_cast<int>(i);
+  if (col < 0) throw std::runtime_error("smmc: " + csv_fpath + " has no column named returns");
+  std::vector<float> out;
+  while (std::getline(in, line)) {
+    const auto cells = split(line);
+    if (static_cast<size_t>(col) >= cells.size()) continue;
+    const std::string cell = trim(cells[col]);
+    if (cell.empty() || cell == "nan" || cell == "NaN") continue;
+    out.push_back(std::strtof(cell.c_str(), nullptr));
+  }
+  return out;
+}
+
+// ---- engines -----------------------------------------------------------------------------------
+
+void mc_simulations(std::atomic<long> &n_simulations, long max_n_simulations, unsigned int n_periods,
+                    float initial_capital, std::vector<float> &historical_returns,
+                    std::vector<float> &final_values) {
+  if (max_n_simulations < 0) throw std::invalid_argument("smmc: negative max_n_simulations");
+  if (final_values.size() < static_cast<size_t>(max_n_simulations))
+    throw std::length_error("smmc: final_values must be pre-sized to max_n_simulations (src/simulations.cpp:252)");
+  run_final_values(n_simulations, max_n_simulations, n_periods, initial_capital, SMMC_MODE_TABLE,
+                   &historical_returns, 0.f, 0.f, final_values.data(), 1);
+}
+
+void mc_simulations_keepdata(std::atomic<long> &n_simulations, long max_n_simulations, unsigned int n_periods,
+                             float initial_capital, std::vector<float> &historical_returns,
+                             std::vector<std::vector<float>> &mc_data, std::vector<float> &final_values) {
+  if (max_n_simulations < 0) throw std::invalid_argument("smmc: negative max_n_simulations");
+  const size_t n = static_cast<size_t>(max_n_simulations);
+  if (final_values.size() < n || mc_data.size() < n)
+    throw std::length_error("smmc: mc_data and final_values must be pre-sized (src/simulations.cpp:183-184)");
+  n_simulations = 0;
+  const size_t row = static_cast<size_t>(n_periods) + 1;
+  // slices bound the flat host staging buffer (~256 MiB) before rows go to their vectors
+  const size_t slice = std::max<size_t>(1, (size_t(1) << 26) / row);
+  std::vector<float> flat(std::min(n, slice) * row);
+  const std::uint64_t seed = next_seed();
+  Session ses(0, &historical_returns);
+  for (size_t first = 0; first < n; first += slice) {
+    const size_t count = std::min(slice, n - first);
+    smmc_sim sim = make_sim(SMMC_MODE_TABLE, seed, first, count, n_periods, initial_capital);
+    check(smmc_engine_simulate_keepdata_to_host(ses.engine, &sim, flat.data(), final_values.data() + first));
+    for (size_t i = 0; i < count; ++i) mc_data[first + i].assign(flat.begin() + i * row, flat.begin() + (i + 1) * row);
+    n_simulations += static_cast<long>(count);  // src/simulations.cpp:190
+  }
+}
+
+void mc_simulations_gpu(std::atomic<long> &n_simulations, long max_n_simulations, int n_periods,
+                        float initial_capital, std::vector<float> &returns, std::vector<float> &totals,
+                        int n_gpus) {
+  if (max_n_simulations < 0 || n_periods < 0) throw std::invalid_argument("smmc: negative size");
+  totals.resize(static_cast<size_t>(max_n_simulations));  // callee-owned result, src/simulations.cu:643-644
+  run_final_values(n_simulations, max_n_simulations, static_cast<unsigned>(n_periods), initial_capital,
+                   SMMC_MODE_TABLE, &returns, 0.f, 0.f, totals.data(), n_gpus);
+}
+
+void mc_simulations_gpu_reduceBlock(std::atomic<long> &n_simulations, long max_n_simulations, int n_periods,
+                                    float initial_capital, std::vector<float> &returns,
+                                    std::vector<float> &means, std::vector<float> &variances, int n_gpus) {
+  if (n_gpus != 1)  // src/simulations.cu:693
+    throw std::invalid_argument("mc_simulations_gpu_reduceBlock: only 1 GPU supported");
+  if (max_n_simulations < 0 || n_periods < 0) throw std::invalid_argument("smmc: negative size");
+  const size_t n_chunks = (static_cast<size_t>(max_n_simulations) + SMMC_CHUNK - 1) / SMMC_CHUNK;
+  means.assign(n_chunks, 0.f);  // src/simulations.cu:429-432
+  variances.assign(n_chunks, 0.f);
+  n_simulations = 0;
+  Session ses(0, &returns);
+  smmc_sim sim = make_sim(SMMC_MODE_TABLE, next_seed(), 0, static_cast<std::uint64_t>(max_n_simulations),
+                          static_cast<unsigned>(n_periods), initial_capital);
+  check(smmc_engine_simulate_to_host(ses.engine, &sim, nullptr, means.data(), variances.data(), nullptr, nullptr, nullptr));
+  n_simulations = max_n_simulations;  // src/simulations.cu:695
+}
+
+// ---- additions -----------------------------------------------------------------------------------
+
+namespace smmc {
+
+void fix_seed(bool fixed, std::uint64_t seed) {
+  std::lock_guard<std::mutex> lock(g_seed_mutex);
+  g_seed_fixed = fixed;
+  g_seed = seed;
+}
+
+void mc_simulations_gpu_gaussian(std::atomic<long> &n_simulations, long max_n_simulations, int n_periods,
+                                 float initial_capital, float return_mean, float return_std,
+                                 std::vector<float> &totals, int n_gpus) {
+  if (max_n_simulations < 0 || n_periods < 0) throw std::invalid_argument("smmc: negative size");
+  totals.resize(static_cast<size_t>(max_n_simulations));
+  run_final_values(n_simulations, max_n_simulations, static_cast<unsigned>(n_periods), initial_capital,
+                   SMMC_MODE_GAUSSIAN, nullptr, return_mean, return_std, totals.data(), n_gpus);
+}
+
+double Summary::stddev() const {
+  if (!count) return 0.0;
+  const double m = mean();
+  return std::sqrt(std::max(sumsq / double(count) - m * m, 0.0));
+}
+
+Summary mc_summary(long max_n_simulations, int n_periods, float initial_capital, bool gaussian,
+                   std::vector<float> &returns, float return_mean, float return_std, float below_threshold,
+                   unsigned n_bins, float hist_lo, float hist_hi, int n_gpus) {
+  if (max_n_simulations < 0 || n_periods < 0) throw std::invalid_argument("smmc: negative size");
+  const std::uint64_t seed = next_seed();
+  const size_t rec = static_cast<size_t>(smmc_stats_bytes(n_bins));
+  std::vector<std::vector<char>> records(n_gpus > 0 ? n_gpus : 1, std::vector<char>(rec));
+  for_each_shard(max_n_simulations, n_gpus, [&](int dev, std::uint64_t first, std::uint64_t count) {
+    Session ses(dev, gaussian ? nullptr : &returns);
+    smmc_sim sim = make_sim(gaussian ? SMMC_MODE_GAUSSIAN : SMMC_MODE_TABLE, seed, first, count,
+                            static_cast<unsigned>(n_periods), initial_capital);
+    sim.gauss_mean = return_mean;
+    sim.gauss_std = return_std;
+    sim.below_threshold = below_threshold;
+    sim.n_bins = n_bins;
+    sim.hist_lo = hist_lo;
+    sim.hist_hi = hist_hi;
+    smmc_stats *hdr = reinterpret_cast<smmc_stats *>(records[dev].data());
+    check(smmc_engine_simulate_to_host(ses.engine, &sim, nullptr, nullptr, nullptr, nullptr, hdr,
+                                       reinterpret_cast<uint64_t *>(records[dev].data() + sizeof(smmc_stats))));
+    hdr->n_bins = n_bins;
+  });
+  for (int g = 1; g < n_gpus; ++g) check(smmc_stats_merge(records[0].data(), records[g].data()));  // device order
+  const smmc_stats *h = reinterpret_cast<const smmc_stats *>(records[0].data());
+  Summary out;
+  out.count = h->count;
+  out.below = h->below;
+  out.underflow = h->underflow;
+  out.overflow = h->overflow;
+  out.sum = h->sum;
+  out.sumsq = h->sumsq;
+  out.min = h->min;
+  out.max = h->max;
+  const uint64_t *bins = reinterpret_cast<const uint64_t *>(h + 1);
+  out.hist.assign(bins, bins + n_bins);
+  return out;
+}
+
+std::vector<float> bundled_synthetic_returns() {
+  static const float table[] = {
+#include "smmc_synthetic_table.inc"
+  };
+  return std::vector<float>(table, table + sizeof(table) / sizeof(table[0]));
+}
+
+}  // namespace smmc

@@ -194,22 +194,35 @@ class Engine:
                 C.c_void_p(final.data_ptr()) if final is not None else None))
         return traj, final
 
-    def simulate_to_host(self, sim, out=None, want_stats=False, progress=None):
-        """Final values straight into host memory (chunked, D2H overlapped with compute)."""
+    def simulate_to_host(self, sim, out=None, want_stats=False, want_chunk_stats=False, progress=None):
+        """Final values (and optionally per-256-path means/variances) straight into host
+        memory: chunked, D2H overlapped with compute.  Returns (final, stats, (means, vars))."""
         n = int(sim.n_paths)
         host = out if out is not None else np.empty(n, dtype=np.float32)
         assert host.dtype == np.float32 and host.size >= n and host.flags.c_contiguous
         st = _lib.Stats()
         hist = np.zeros(max(int(sim.n_bins), 1), dtype=np.uint64)
+        nc = (n + _lib.CHUNK - 1) // _lib.CHUNK
+        cm = np.empty(nc, dtype=np.float32) if want_chunk_stats else None
+        cv = np.empty(nc, dtype=np.float32) if want_chunk_stats else None
         prog = progress if progress is not None else C.c_int64(0)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
         _lib.check(self._L.smmc_engine_simulate_to_host(
-            self._h, C.byref(sim), host.ctypes.data_as(C.c_void_p), C.byref(prog),
-            C.byref(st) if want_stats else None, hist.ctypes.data_as(C.c_void_p) if want_stats else None))
+            self._h, C.byref(sim), vp(host), vp(cm), vp(cv), C.byref(prog),
+            C.byref(st) if want_stats else None, vp(hist) if want_stats else None))
         stats = None
         if want_stats:
             stats = Stats(st.count, st.below, st.underflow, st.overflow, st.sum, st.sumsq, st.min, st.max,
                           hist[: int(sim.n_bins)])
-        return host, stats
+        return host, stats, (cm, cv)
+
+    def simulate_keepdata_to_host(self, sim):
+        n, p = int(sim.n_paths), int(sim.n_periods)
+        traj = np.empty((n, p + 1), dtype=np.float32)
+        final = np.empty(n, dtype=np.float32)
+        _lib.check(self._L.smmc_engine_simulate_keepdata_to_host(
+            self._h, C.byref(sim), traj.ctypes.data_as(C.c_void_p), final.ctypes.data_as(C.c_void_p)))
+        return traj, final
 
 
 # ---------------------------------------------------------------------------
@@ -294,7 +307,7 @@ def mc_simulations(max_n_simulations, n_periods, initial_capital, historical_ret
     e = _engine(0)
     e.set_table(historical_returns)
     sim = Engine.make_sim(n, n_periods, MODE_TABLE, _seed(seed), initial_capital=initial_capital)
-    out, _ = e.simulate_to_host(sim, out=final_values)
+    out, _, _ = e.simulate_to_host(sim, out=final_values)
     return out[:n]
 
 
@@ -307,6 +320,7 @@ def mc_simulations_gpu_reduceBlock(max_n_simulations, n_periods, initial_capital
     e.set_table(returns)
     sim = Engine.make_sim(int(max_n_simulations), n_periods, MODE_TABLE, _seed(seed), initial_capital=initial_capital)
     r = e.simulate(sim, want_final=False, want_chunk_stats=True)
+    e.sync()
     return r.chunk_mean.cpu().numpy(), r.chunk_var.cpu().numpy()
 
 
@@ -315,5 +329,4 @@ def mc_simulations_keepdata(max_n_simulations, n_periods, initial_capital, histo
     e = _engine(0)
     e.set_table(historical_returns)
     sim = Engine.make_sim(int(max_n_simulations), n_periods, MODE_TABLE, _seed(seed), initial_capital=initial_capital)
-    traj, final = e.simulate_keepdata(sim)
-    return traj.cpu().numpy(), final.cpu().numpy()
+    return e.simulate_keepdata_to_host(sim)

@@ -1,0 +1,82 @@
+// dropin_check.cpp -- exercises the reference-named C++ API (simulations.h) the way the
+// reference's callers do and prints one JSON object for tests/test_dropin_gpu.py.
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <thread>
+
+#include "stock_market_monte_carlo/simulations.h"
+
+static std::uint64_t fnv(const std::vector<float> &v) {
+  std::uint64_t h = 0xCBF29CE484222325ull;
+  for (float f : v) {
+    unsigned char b[4];
+    std::memcpy(b, &f, 4);
+    for (unsigned char c : b) h = (h ^ c) * 0x100000001B3ull;
+  }
+  return h;
+}
+
+int main(int argc, char **argv) {
+  const long n = argc > 1 ? std::atol(argv[1]) : 20000;
+  const int periods = argc > 2 ? std::atoi(argv[2]) : 36;
+  std::vector<float> table = read_historical_returns("data/SP500_monthly_returns.csv");
+  smmc::fix_seed(true, 4242);
+  std::atomic<long> counter{0};
+
+  std::vector<float> gpu_totals;  // callee sizes it
+  mc_simulations_gpu(counter, n, periods, 1000.f, table, gpu_totals, 1);
+  const long counter_gpu = counter;
+
+  std::vector<float> cpu_final(n, 1000.f);  // caller sizes it
+  long seen_mid = -1;
+  {
+    // the reference's GUI polls n_simulations from another thread while the engine runs
+    std::atomic<bool> done{false};
+    std::thread poll([&] { while (!done) { long c = counter; if (c > 0 && c < n) seen_mid = c; std::this_thread::yield(); } });
+    mc_simulations(counter, n, static_cast<unsigned>(periods), 1000.f, table, cpu_final);
+    done = true;
+    poll.join();
+  }
+
+  std::vector<float> means, variances;
+  mc_simulations_gpu_reduceBlock(counter, n, periods, 1000.f, table, means, variances, 1);
+  bool threw = false;
+  try {
+    mc_simulations_gpu_reduceBlock(counter, n, periods, 1000.f, table, means, variances, 2);
+  } catch (const std::invalid_argument &) {
+    threw = true;
+  }
+
+  const long nk = n < 3000 ? n : 3000;
+  std::vector<std::vector<float>> mc_data(nk);
+  std::vector<float> keep_final(nk, -1.f);
+  mc_simulations_keepdata(counter, nk, static_cast<unsigned>(periods), 1000.f, table, mc_data, keep_final);
+  bool rows_ok = true;
+  for (long i = 0; i < nk; ++i)
+    rows_ok = rows_ok && mc_data[i].size() == size_t(periods) + 1 && mc_data[i][0] == 1000.f && mc_data[i].back() == keep_final[i];
+  // a trajectory is many_updates of something: re-run the recurrence from its own ratios is not possible,
+  // so check the chain with update_fund on the implied returns instead (values[i+1] = update_fund(values[i], r))
+  std::vector<float> rets = {1.f, -2.f, 3.5f};
+  std::vector<float> mu = many_updates(1000.f, rets, 3u);
+  std::vector<float> mu_long = many_updates(1000.f, rets, 3l);
+
+  std::vector<float> gauss;
+  smmc::mc_simulations_gpu_gaussian(counter, n, periods, 1000.f, 0.5f, 0.83333f, gauss, 1);
+  smmc::Summary s = smmc::mc_summary(n, periods, 1000.f, true, table, 0.5f, 0.83333f, 1000.f, 50, 0.f, 5000.f, 1);
+  std::uint64_t hist_total = 0;
+  for (auto c : s.hist) hist_total += c;
+
+  std::printf("{\"n\": %ld, \"gpu_hash\": %" PRIu64 ", \"cpu_hash\": %" PRIu64 ", \"counter_gpu\": %ld, \"seen_mid\": %ld, "
+              "\"n_means\": %zu, \"mean0\": %.9g, \"var0\": %.9g, \"threw\": %s, \"rows_ok\": %s, \"keep_hash\": %" PRIu64 ", "
+              "\"mu\": [%.9g, %.9g, %.9g, %.9g], \"mu_long_same\": %s, \"update_fund\": %.9g, "
+              "\"gauss_hash\": %" PRIu64 ", \"sum_count\": %" PRIu64 ", \"sum_mean\": %.17g, \"sum_below\": %" PRIu64 ", \"hist_total\": %" PRIu64 ", "
+              "\"bundled\": %zu, \"sample_hist\": %zu, \"sample_gauss\": %zu}\n",
+              n, fnv(gpu_totals), fnv(cpu_final), counter_gpu, seen_mid, means.size(), means[0], variances[0],
+              threw ? "true" : "false", rows_ok ? "true" : "false", fnv(keep_final), mu[0], mu[1], mu[2], mu[3],
+              mu == mu_long ? "true" : "false", update_fund(1000.f, 0.5f), fnv(gauss), s.count, s.mean(), s.below,
+              hist_total + s.underflow + s.overflow, smmc::bundled_synthetic_returns().size(),
+              sample_returns_historical(17, table).size(), sample_returns_gaussian(9, 0.5f, 0.8f).size());
+  return 0;
+}

@@ -1,0 +1,85 @@
+"""The N > 1 path on CPU: world_size-2 and -3 gloo groups exchange per-shard statistics
+records (built by the oracle for each rank's path range) through the product's
+gather-and-merge, and must reproduce the oracle's whole-run statistics."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _record_from_oracle(O, _lib, mode, n_periods, first, count, table, n_bins, lo, hi):
+    p = O.make_params(mode, n_periods, count, 1234, first_path=first, table=table, n_bins=n_bins, hist_lo=lo, hist_hi=hi)
+    r = O.counter_mc(p)
+    st = r["stats"]
+    hdr = _lib.Stats(st.count, st.below, st.underflow, st.overflow, st.sum, st.sumsq, st.min, st.max, n_bins, 0)
+    return bytes(hdr) + r["hist"].astype(np.uint64).tobytes()
+
+
+def _worker(rank, world, port, n_total, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from stock_market_monte_carlo_amd import _lib
+    from stock_market_monte_carlo_amd.dist import all_gather_merge_stats, shard_range
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_table
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    table = load_table()
+    first, count = shard_range(n_total, world, rank)
+    rec = _record_from_oracle(O, _lib, O.MODE_GAUSSIAN, 24, first, count, table, 32, 0.0, 3000.0)
+    t = torch.frombuffer(bytearray(rec), dtype=torch.uint8)
+    merged = all_gather_merge_stats(t)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"),
+            np.array([merged.count, merged.below, merged.underflow, merged.overflow, merged.sum, merged.sumsq,
+                      merged.min, merged.max] + merged.hist.tolist(), dtype=np.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_gather_merge_matches_whole_run(world, tmp_path, oracle, table):
+    from stock_market_monte_carlo_amd import _lib
+    _lib.lib()
+    n_total = 10007  # not divisible by 2 or 3: the remainder must not be dropped
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    whole = oracle.counter_mc(oracle.make_params(oracle.MODE_GAUSSIAN, 24, n_total, 1234, table=table, n_bins=32,
+                                                 hist_lo=0.0, hist_hi=3000.0))
+    st = whole["stats"]
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"r{r}.npy"))
+        assert got[0] == n_total == st.count
+        assert (got[1], got[2], got[3]) == (st.below, st.underflow, st.overflow)
+        assert got[4] == pytest.approx(st.sum, rel=1e-13) and got[5] == pytest.approx(st.sumsq, rel=1e-13)
+        assert got[6] == st.min and got[7] == st.max
+        assert np.array_equal(got[8:].astype(np.uint64), whole["hist"])
+    # every rank merged in the same (rank) order: bit-identical results everywhere
+    a = np.load(os.path.join(str(tmp_path), "r0.npy"))
+    for r in range(1, world):
+        assert np.array_equal(a, np.load(os.path.join(str(tmp_path), f"r{r}.npy")))
+
+
+def test_shard_ranges_tile_the_path_space():
+    from stock_market_monte_carlo_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 1000003, 10 ** 9):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for r in range(world):
+                first, count = shard_range(n, world, r)
+                assert first == nxt and count >= 0
+                nxt += count
+            assert nxt == n
+            counts = [shard_range(n, world, r)[1] for r in range(world)]
+            assert max(counts) - min(counts) <= 1

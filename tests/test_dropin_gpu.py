@@ -1,0 +1,92 @@
+"""The C++ drop-in layer (include/stock_market_monte_carlo/simulations.h) and the
+benchmark_mc_* programs on the GPU, checked against the Python path and the oracle."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "stock_market_monte_carlo_amd")
+
+
+def fnv(a):
+    h = 0xCBF29CE484222325
+    for b in np.ascontiguousarray(a, dtype=np.float32).tobytes():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.fixture(scope="module")
+def built():
+    from stock_market_monte_carlo_amd import build
+    build.build()
+    build.build_cli()
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "dropin_check.cpp"), "-o", exe, "-L" + PKG, "-lsmmc_hip",
+                           "-Wl,-rpath," + PKG, "-pthread"])
+    return exe
+
+
+def test_cpp_dropin_matches_python_path_and_oracle(built, oracle, table):
+    import stock_market_monte_carlo_amd as S
+    n, p = 20000, 36
+    out = subprocess.check_output([built, str(n), str(p)], cwd=ROOT)
+    d = json.loads(out.decode().strip().splitlines()[-1])
+    want = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, p, n, 4242, table=table))["final"]
+    assert d["gpu_hash"] == fnv(want) == d["cpu_hash"]            # both reference signatures, same stream
+    assert d["gpu_hash"] == fnv(S.mc_simulations_gpu(n, p, 1000.0, table, seed=4242))
+    assert d["counter_gpu"] == n
+    cm, cv = oracle.chunk_mean_var(want)
+    assert d["n_means"] == (n + 255) // 256
+    assert d["mean0"] == pytest.approx(float(cm[0]), rel=1e-6) and d["var0"] == pytest.approx(float(cv[0]), rel=1e-5)
+    assert d["threw"] and d["rows_ok"]
+    assert d["keep_hash"] == fnv(want[:3000])
+    assert np.array_equal(np.array(d["mu"], dtype=np.float32), oracle.many_updates(1000.0, [1.0, -2.0, 3.5], 3))
+    assert d["mu_long_same"]
+    assert d["update_fund"] == 1005.0
+    g = oracle.counter_mc(oracle.make_params(oracle.MODE_GAUSSIAN, p, n, 4242, n_bins=50, hist_lo=0.0, hist_hi=5000.0))
+    assert d["gauss_hash"] == fnv(g["final"])
+    assert d["sum_count"] == n == d["hist_total"] and d["sum_below"] == g["stats"].below
+    assert d["sum_mean"] == pytest.approx(g["stats"].sum / n, rel=1e-12)
+    assert d["bundled"] == 1127 and d["sample_hist"] == 17 and d["sample_gauss"] == 9
+
+
+def _run(prog, *args, env=None):
+    e = dict(os.environ, SMMC_SEED="99", **(env or {}))
+    return subprocess.run([os.path.join(PKG, "bin", prog), *map(str, args)], cwd=ROOT, env=e, capture_output=True,
+                          text=True)
+
+
+def test_benchmark_mc_gpu_cli_prints_reference_lines(built, oracle, table):
+    r = _run("benchmark_mc_gpu", 1, 360, 200000)
+    assert r.returncode == 0, r.stderr
+    assert "n_periods: 360 | max_n_simulations: 200000" in r.stdout
+    assert re.search(r"All 200000 simulation done in [0-9.e+-]+ s!", r.stdout)
+    m = re.search(r"mean: ([0-9.]+) \| std: ([0-9.]+)", r.stdout)
+    c = re.search(r"count_below 1000.0: ([0-9,]+) \(([0-9.]+)%\)", r.stdout)
+    want = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 360, 200000, 99, table=table))["final"]
+    mean = float(np.float32(want.astype(np.float64).sum() / want.size))
+    assert float(m.group(1)) == pytest.approx(mean, abs=0.006)
+    assert int(c.group(1).replace(",", "")) == int((want < 1000.0).sum())
+    # Gaussian mode through the same program
+    r = _run("benchmark_mc_gpu", 1, 360, 100000, env={"SMMC_MODE": "gaussian", "SMMC_JSON": "1"})
+    assert r.returncode == 0 and '"program": "benchmark_mc_gpu"' in r.stdout
+
+
+def test_other_clis_run(built):
+    r = _run("benchmark_mc_gpu_reduceBlock", 1, 360, 100000)
+    assert r.returncode == 0 and "n_simulations: 100000" in r.stdout and "prob below min" in r.stdout
+    assert "exact (fused on-device reduction" in r.stdout
+    r = _run("benchmark_mc_gpu_reduceBlock", 2, 360, 1000)  # std::invalid_argument in the reference (simulations.cu:693)
+    assert r.returncode == 1 and "only 1 GPU" in r.stderr
+    r = _run("benchmark_mc_cpu_v2", 360, 100000)
+    assert r.returncode == 0 and re.search(r"All 100000 simulation done in", r.stdout)
+    r = _run("benchmark_mc_cpu", 360, 20000)
+    assert r.returncode == 0 and re.search(r"All 20000 simulation done in", r.stdout)
+    r = _run("benchmark_mc_gpu", 1, 360, 5000, env={"SMMC_TABLE": "/nonexistent.csv"})
+    assert r.returncode == 0 and "bundled SYNTHETIC table (1127 entries)" in r.stdout

@@ -191,9 +191,10 @@ def test_simulate_to_host_pipeline_matches_device_path(eng, table):
     from stock_market_monte_carlo_amd import Engine, MODE_TABLE
     n = (1 << 24) * 2 + 12345
     sim = Engine.make_sim(n, 4, MODE_TABLE, 3, n_bins=50, hist_lo=800, hist_hi=1300)
-    host, st = eng.simulate_to_host(sim, want_stats=True)
-    dev = eng.simulate(sim, want_stats=True)
+    host, st, (cm, cv) = eng.simulate_to_host(sim, want_stats=True, want_chunk_stats=True)
+    dev = eng.simulate(sim, want_stats=True, want_chunk_stats=True)
     assert np.array_equal(host.view(np.uint32), dev.final.cpu().numpy().view(np.uint32))
+    assert np.array_equal(cm, dev.chunk_mean.cpu().numpy()) and np.array_equal(cv, dev.chunk_var.cpu().numpy())
     w = eng.read_stats(dev.stats_raw)
     assert st.count == n and np.array_equal(st.hist, w.hist) and st.below == w.below
     assert st.sum == pytest.approx(w.sum, rel=1e-12)
