@@ -36,9 +36,11 @@ PATHS_PER_GPU = 100_000_000
 SEED = 0x5EED5EED5EED5EED
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock = 7.86e13 lane-ops/s
-# VALU lane-ops per path-period issued by paths_kernel (counted from the gfx950 ISA,
-# DESIGN.md section 5; quarter-rate integer multiplies counted as 4)
-VALU_SLOTS_PER_STEP = {"gaussian": 62.0, "table": 39.0}
+# VALU work per path-period of paths_kernel's inner loop, from the gfx950 ISA
+# (tools/isa_loop_count.py): instructions, and issue units where a
+# plain VALU op = 1 and multi-cycle ones carry their measured cost (mad_u64 2.05, ...)
+VALU_INSTS_PER_STEP = {"gaussian": 159 / 4, "table": 62 / 4}
+VALU_UNITS_PER_STEP = {"gaussian": 51.1, "table": 21.6}
 
 
 def load_table():
@@ -188,8 +190,9 @@ def main():
         k_avg_s = kernel_ms / 1e3 / max(launches, 1)
         bytes_per_launch = 4.0 * n if want_final else 0.0
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
-        slots = VALU_SLOTS_PER_STEP[args.mode]
-        valu_ach = n * args.periods * slots / k_avg_s if k_avg_s > 0 else 0.0
+        insts, units = VALU_INSTS_PER_STEP[args.mode], VALU_UNITS_PER_STEP[args.mode]
+        valu_ach = n * args.periods * insts / k_avg_s if k_avg_s > 0 else 0.0
+        valu_w = n * args.periods * units / k_avg_s if k_avg_s > 0 else 0.0
         out = {
             "metric": "simulated paths/sec at N=360 periods" if args.periods == 360
                       else f"simulated paths/sec at N={args.periods} periods",
@@ -207,7 +210,8 @@ def main():
                          "note": "VALU-bound kernel: 4 B of HBM traffic per 360-period path by construction; "
                                  "see valu"},
             "valu": {"bound": "valu-issue", "achieved": valu_ach, "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s",
-                     "frac": valu_ach / VALU_PEAK_LANEOPS, "slots_per_path_period": slots},
+                     "frac": valu_ach / VALU_PEAK_LANEOPS, "insts_per_path_period": insts,
+                     "issue_weighted_frac": valu_w / VALU_PEAK_LANEOPS, "issue_units_per_path_period": units},
         }
         if stats is not None:
             out["result"] = {"mean": stats.mean, "std": stats.std, "below_initial": stats.below,

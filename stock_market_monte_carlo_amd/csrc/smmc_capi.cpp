@@ -68,6 +68,7 @@ struct smmc_engine {
   hipStream_t copy_stream = nullptr;  // lazily created, simulate_to_host only
   uint32_t compute_units = 0;
   uint32_t max_grid = 0;
+  uint32_t keepdata_blocks_per_cu = 16;
   size_t max_lds = 0;
 
   float *d_table = nullptr;  // 100.0f + r
@@ -272,6 +273,10 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     if (v >= 1 && v <= 4096) blocks_per_cu = static_cast<uint32_t>(v);
   }
   e->max_grid = e->compute_units * blocks_per_cu;
+  if (const char *env = std::getenv("SMMC_KEEPDATA_BLOCKS_PER_CU")) {
+    const long v = std::strtol(env, nullptr, 10);
+    if (v >= 1 && v <= 4096) e->keepdata_blocks_per_cu = static_cast<uint32_t>(v);
+  }
   e->max_lds = prop.sharedMemPerBlock;
   if (stream != SMMC_STREAM_NEW) {
     e->stream = static_cast<hipStream_t>(stream);  // NULL = the default stream
@@ -368,12 +373,19 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   const uint64_t n_chunks = (sim->n_paths + smmc::kBlock - 1) / smmc::kBlock;
   const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid));
   if (grid == 0) return SMMC_OK;
-  const size_t lds = smmc::keepdata_lds_bytes(a.table_len);
+  int tile = 32;  // periods per LDS tile (16 | 32 | 64)
+  if (const char *env = std::getenv("SMMC_KEEPDATA_TILE")) {  // tuning knob, results do not depend on it
+    const long v = std::strtol(env, nullptr, 10);
+    if (v == 16 || v == 32 || v == 64) tile = static_cast<int>(v);
+  }
+  while (tile > 16 && smmc::keepdata_lds_bytes(a.table_len, tile) > e->max_lds) tile /= 2;
+  const size_t lds = smmc::keepdata_lds_bytes(a.table_len, tile);
   if (lds > e->max_lds)
     return fail(SMMC_ERR_INVALID, "keepdata needs %zu bytes of LDS, device allows %zu", lds, e->max_lds);
+  const uint32_t kgrid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->compute_units * e->keepdata_blocks_per_cu));
   rc = timing_begin(e);
   if (rc) return rc;
-  SMMC_HIP(smmc::launch_keepdata(a, !fast_div_is_safe(e, sim), grid, lds, e->stream));
+  SMMC_HIP(smmc::launch_keepdata(a, !fast_div_is_safe(e, sim), tile, kgrid, e->stream));
   return timing_end(e);
 }
 

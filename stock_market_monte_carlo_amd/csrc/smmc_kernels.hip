@@ -401,15 +401,16 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const BlockPartial *pa
 // mc_data of mc_simulations_keepdata (src/simulations.cpp:139-186): row i holds the
 // n_periods + 1 values of path i (values[0] = initial capital).  This one IS
 // HBM-bound: 4 (P + 1) bytes per path.  A lane owns a path, so one period's values
-// of a wave form a column of the output; the wave parks 64 periods x 64 paths in a
-// private LDS tile and then writes each path's 64 values as one contiguous 256-byte
-// run.  Tile rows are padded by one word: column writes (stride 65) and row reads
-// are both bank-conflict free.
-constexpr int kTile = 64;            // periods per LDS tile = 16 Philox blocks
-constexpr int kTilePad = kTile + 1;
-
-template <int kMode, bool kExactDiv>
+// of a wave form a column of the output; the wave parks kTile periods x 64 paths in a
+// private LDS tile and then writes them out row by row, kTile contiguous floats per
+// path.  Tile rows are padded by one word: column writes (stride kTile + 1) and row
+// reads are both bank-conflict free.  The tile size trades run length per row
+// (kTile * 4 bytes) against LDS per workgroup, i.e. waves per CU that overlap one
+// wave's store phase with another's compute phase.
+template <int kMode, bool kExactDiv, int kTile>
 __global__ __launch_bounds__(kBlock) void keepdata_kernel(const KernelArgs k) {
+  constexpr int kTilePad = kTile + 1;
+  constexpr int kRowsPerStore = 64 / kTile;  // rows covered by one wave-wide store
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float *lds_table = reinterpret_cast<float *>(lds_raw);
   const uint32_t table_words = (kMode == SMMC_MODE_TABLE) ? k.table_len : 0u;
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(kBlock) void keepdata_kernel(const KernelArgs k) {
   }
   __syncthreads();
 
+  const uint32_t sub_row = lane / kTile, col = lane % kTile;  // this lane's place in a store
   const uint64_t row_len = static_cast<uint64_t>(k.n_periods) + 1;
   const uint64_t n_chunks = (k.n_paths + kBlock - 1) / kBlock;
   for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -451,9 +453,26 @@ __global__ __launch_bounds__(kBlock) void keepdata_kernel(const KernelArgs k) {
       // The tile is private to this wave: order LDS writes before the row reads.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (lane < cols) {
-        float *dst = k.d_traj + wave_first * row_len + 1 + p0 + lane;
-        for (uint32_t r = 0; r < rows_here; ++r) dst[r * row_len] = tile[r * kTilePad + lane];
+      {
+        float *dst = k.d_traj + (wave_first + sub_row) * row_len + 1 + p0 + col;
+        const float *src = tile + sub_row * kTilePad + col;
+        const uint64_t dst_step = static_cast<uint64_t>(kRowsPerStore) * row_len;
+        constexpr int kUnroll = 4;
+        uint32_t r = 0;
+        if (col < cols) {
+          for (; r + kUnroll * kRowsPerStore <= rows_here; r += kUnroll * kRowsPerStore) {
+            float v[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) v[u] = src[(r + u * kRowsPerStore) * kTilePad];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) dst[u * dst_step] = v[u];
+            dst += kUnroll * dst_step;
+          }
+          for (; r < rows_here; r += kRowsPerStore) {
+            if (r + sub_row < rows_here) *dst = src[r * kTilePad];
+            dst += dst_step;
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -494,8 +513,8 @@ hipError_t launch_selftest(uint32_t lo, uint32_t hi, unsigned long long *d_count
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins) {
   return (static_cast<size_t>(table_len) + n_bins) * 4u;
 }
-size_t keepdata_lds_bytes(uint32_t table_len) {
-  return (static_cast<size_t>(table_len) + static_cast<size_t>(kWaves) * 64 * kTilePad) * 4u;
+size_t keepdata_lds_bytes(uint32_t table_len, int tile) {
+  return (static_cast<size_t>(table_len) + static_cast<size_t>(kWaves) * 64 * (tile + 1)) * 4u;
 }
 
 template <int kMode>
@@ -521,20 +540,31 @@ hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, sm
   return hipGetLastError();
 }
 
-template <int kMode>
-static hipError_t launch_keepdata_mode(const KernelArgs &a, bool exact_div, uint32_t grid, size_t lds,
+template <int kMode, int kTile>
+static hipError_t launch_keepdata_tile(const KernelArgs &a, bool exact_div, uint32_t grid, size_t lds,
                                        hipStream_t stream) {
   if (exact_div)
-    hipLaunchKernelGGL((keepdata_kernel<kMode, true>), dim3(grid), dim3(kBlock), lds, stream, a);
+    hipLaunchKernelGGL((keepdata_kernel<kMode, true, kTile>), dim3(grid), dim3(kBlock), lds, stream, a);
   else
-    hipLaunchKernelGGL((keepdata_kernel<kMode, false>), dim3(grid), dim3(kBlock), lds, stream, a);
+    hipLaunchKernelGGL((keepdata_kernel<kMode, false, kTile>), dim3(grid), dim3(kBlock), lds, stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_keepdata(const KernelArgs &a, bool exact_div, uint32_t grid, size_t lds_bytes,
-                           hipStream_t stream) {
-  return a.mode == SMMC_MODE_TABLE ? launch_keepdata_mode<SMMC_MODE_TABLE>(a, exact_div, grid, lds_bytes, stream)
-                   : launch_keepdata_mode<SMMC_MODE_GAUSSIAN>(a, exact_div, grid, lds_bytes, stream);
+template <int kMode>
+static hipError_t launch_keepdata_mode(const KernelArgs &a, bool exact_div, int tile, uint32_t grid,
+                                       hipStream_t stream) {
+  const size_t lds = keepdata_lds_bytes(a.table_len, tile);
+  switch (tile) {
+    case 16: return launch_keepdata_tile<kMode, 16>(a, exact_div, grid, lds, stream);
+    case 32: return launch_keepdata_tile<kMode, 32>(a, exact_div, grid, lds, stream);
+    case 64: return launch_keepdata_tile<kMode, 64>(a, exact_div, grid, lds, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_keepdata(const KernelArgs &a, bool exact_div, int tile, uint32_t grid, hipStream_t stream) {
+  return a.mode == SMMC_MODE_TABLE ? launch_keepdata_mode<SMMC_MODE_TABLE>(a, exact_div, tile, grid, stream)
+                                   : launch_keepdata_mode<SMMC_MODE_GAUSSIAN>(a, exact_div, tile, grid, stream);
 }
 
 }  // namespace smmc

@@ -1,0 +1,58 @@
+"""CPU proofs behind the device-side arithmetic shortcuts, using the
+oracle's scanners: the shortcuts themselves are re-stated there with fmaf()."""
+import struct
+
+import numpy as np
+
+
+def bits(f):
+    return struct.unpack("<I", struct.pack("<f", f))[0]
+
+
+def test_div100_shortcut_is_exact_on_its_whole_domain(oracle):
+    """q = x*c; e = fma(-100, q, x); q' = fma(e, c, q) equals x / 100.0f for EVERY binary32
+    with |x| >= 2^-124 (all 2.1e9 positive patterns; negatives are symmetric and covered by
+    the device self-test).  It fails only where the quotient is subnormal."""
+    bad, first = oracle.div100_mismatches(bits(2.0 ** -124), 0x7F800000)
+    assert bad == 0, hex(first)
+    assert oracle.div100_mismatches(0, 1)[0] == 0  # +0
+    # and the documented failure region really exists (so the host-side guard is needed)
+    assert oracle.div100_mismatches(bits(2.0 ** -126), bits(2.0 ** -124))[0] > 0
+
+
+def test_log_kernel_never_positive_and_accurate(oracle):
+    """Box-Muller takes sqrt(-2 log_kernel(U1)): the kernel must be <= 0 on every U1 in
+    [2^-33, 1] (all 2.8e8 binary32 values) and close to the true logarithm."""
+    positive, worst = oracle.log_kernel_scan(bits(2.0 ** -33), bits(1.0) + 1)
+    assert positive == 0
+    assert worst < 1e-7
+    assert oracle.lib().orc_log_kernel(1.0) == 0.0
+
+
+def test_box_muller_moments_and_accuracy(oracle):
+    rng = np.random.default_rng(5)
+    ua = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64)
+    ub = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64)
+    z = np.array([oracle.box_muller(int(a), int(b)) for a, b in zip(ua, ub)])
+    r = np.sqrt(-2 * np.log(np.float32(ua).astype(np.float64) * 2.0 ** -32 + 2.0 ** -33))
+    th = 2 * np.pi * ub.astype(np.float64) / 2.0 ** 32
+    assert np.abs(z[:, 0] - r * np.cos(th)).max() < 2e-6
+    assert np.abs(z[:, 1] - r * np.sin(th)).max() < 2e-6
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    # extremes of the input words stay finite
+    for a, b in [(0, 0), (0xFFFFFFFF, 0xFFFFFFFF), (0, 0x80000000), (0xFFFFFFFF, 0x40000000), (1, 0x3FFFFFFF)]:
+        zc, zs = oracle.box_muller(a, b)
+        assert np.isfinite(zc) and np.isfinite(zs) and abs(zc) < 7 and abs(zs) < 7
+    assert oracle.box_muller(0xFFFFFFFF, 123)[0] == 0.0  # U1 rounds to 1 -> radius 0
+
+
+def test_histogram_bucket_contract(oracle):
+    L = oracle.lib()
+    assert L.orc_hist_bucket(-1.0, 0.0, 100.0, 10) == -1
+    assert L.orc_hist_bucket(0.0, 0.0, 100.0, 10) == 0
+    assert L.orc_hist_bucket(9.999999, 0.0, 100.0, 10) == 0
+    assert L.orc_hist_bucket(10.0, 0.0, 100.0, 10) == 1
+    assert L.orc_hist_bucket(99.99999, 0.0, 100.0, 10) == 9
+    assert L.orc_hist_bucket(100.0, 0.0, 100.0, 10) == 10
+    assert L.orc_hist_bucket(float("nan"), 0.0, 100.0, 10) == 10
+    assert L.orc_hist_bucket(float("inf"), 0.0, 100.0, 10) == 10
