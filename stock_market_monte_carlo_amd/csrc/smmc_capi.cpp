@@ -373,12 +373,12 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   const uint64_t n_chunks = (sim->n_paths + smmc::kBlock - 1) / smmc::kBlock;
   const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid));
   if (grid == 0) return SMMC_OK;
-  int tile = 32;  // periods per LDS tile (16 | 32 | 64)
+  int tile = 32;  // columns per LDS tile (32 | 64); 32 measured faster (3.1 vs 2.6 TB/s)
   if (const char *env = std::getenv("SMMC_KEEPDATA_TILE")) {  // tuning knob, results do not depend on it
     const long v = std::strtol(env, nullptr, 10);
-    if (v == 16 || v == 32 || v == 64) tile = static_cast<int>(v);
+    if (v == 32 || v == 64) tile = static_cast<int>(v);
   }
-  while (tile > 16 && smmc::keepdata_lds_bytes(a.table_len, tile) > e->max_lds) tile /= 2;
+  while (tile > 32 && smmc::keepdata_lds_bytes(a.table_len, tile) > e->max_lds) tile /= 2;
   const size_t lds = smmc::keepdata_lds_bytes(a.table_len, tile);
   if (lds > e->max_lds)
     return fail(SMMC_ERR_INVALID, "keepdata needs %zu bytes of LDS, device allows %zu", lds, e->max_lds);

@@ -400,16 +400,26 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const BlockPartial *pa
 //
 // mc_data of mc_simulations_keepdata (src/simulations.cpp:139-186): row i holds the
 // n_periods + 1 values of path i (values[0] = initial capital).  This one IS
-// HBM-bound: 4 (P + 1) bytes per path.  A lane owns a path, so one period's values
-// of a wave form a column of the output; the wave parks kTile periods x 64 paths in a
-// private LDS tile and then writes them out row by row, kTile contiguous floats per
-// path.  Tile rows are padded by one word: column writes (stride kTile + 1) and row
-// reads are both bank-conflict free.  The tile size trades run length per row
-// (kTile * 4 bytes) against LDS per workgroup, i.e. waves per CU that overlap one
-// wave's store phase with another's compute phase.
+// HBM-bound: 4 (P + 1) bytes per path.
+//
+// A lane owns a path, so one period's values of a wave form a COLUMN of the output;
+// rows are 4 (P + 1) bytes apart, i.e. start at arbitrary 4-byte offsets.  Writing
+// tile-aligned runs leaves partial 128-byte lines in L2 for a whole tile time, and
+// their in-flight footprint (~ waves x 16 KB) is the size of the aggregate L2: that
+// version ran at 2.7 TB/s.  Here every lane runs its path with its own DELAY of phi
+// columns, phi = (float address of its row start) mod kTile, so that column c of
+// tile t of EVERY row lands on a float address that is c mod kTile: each wave-wide
+// store covers whole aligned kTile*4-byte windows (256 or 128 bytes), complete lines
+// the moment they are written.  Only the first and last window of a row are partial.
+//
+// Column g of lane r holds value index s = g - phi_r (0 = initial capital, s >= 1 =
+// after period s - 1).  Philox blocks stay wave-uniform in time: at column group G
+// every lane draws block G - q_r, and a two-stage barrel shifter over the previous and
+// current block's multipliers applies the lane's residual shift rho_r in {0,1,2,3}
+// (phi_r + 1 = 4 q_r + rho_r).  Lanes idle (keep their value) outside 1 <= s <= P.
 template <int kMode, bool kExactDiv, int kTile>
 __global__ __launch_bounds__(kBlock) void keepdata_kernel(const KernelArgs k) {
-  constexpr int kTilePad = kTile + 1;
+  constexpr int kTilePad = kTile + 1;        // +1 word: column writes and row reads conflict-free
   constexpr int kRowsPerStore = 64 / kTile;  // rows covered by one wave-wide store
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float *lds_table = reinterpret_cast<float *>(lds_raw);
@@ -422,7 +432,10 @@ __global__ __launch_bounds__(kBlock) void keepdata_kernel(const KernelArgs k) {
   __syncthreads();
 
   const uint32_t sub_row = lane / kTile, col = lane % kTile;  // this lane's place in a store
-  const uint64_t row_len = static_cast<uint64_t>(k.n_periods) + 1;
+  const uint32_t n_periods = k.n_periods;
+  const uint64_t row_len = static_cast<uint64_t>(n_periods) + 1;
+  const uint64_t base_f = reinterpret_cast<uintptr_t>(k.d_traj) >> 2;  // float address of d_traj[0]
+  const uint32_t n_tiles = static_cast<uint32_t>((row_len + (kTile - 1) + (kTile - 1)) / kTile);
   const uint64_t n_chunks = (k.n_paths + kBlock - 1) / kBlock;
   for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint64_t wave_first = chunk * kBlock + wave * 64;  // first path of this wave
@@ -435,43 +448,59 @@ __global__ __launch_bounds__(kBlock) void keepdata_kernel(const KernelArgs k) {
     const uint64_t path = k.first_path + i;
     const uint32_t path_lo = static_cast<uint32_t>(path), path_hi = static_cast<uint32_t>(path >> 32);
 
+    const uint32_t phi = static_cast<uint32_t>(base_f + i * row_len) & (kTile - 1);
+    const uint32_t psi = phi + 1;  // period = column - psi
+    const uint32_t q = psi >> 2;
+    const bool shift1 = (psi & 1u) != 0, shift2 = (psi & 2u) != 0;
+
     float total = k.initial_capital;
-    if (active) k.d_traj[i * row_len] = total;  // values[0]
-    for (uint32_t p0 = 0; p0 < k.n_periods; p0 += kTile) {
-      const uint32_t cols = (k.n_periods - p0) < kTile ? (k.n_periods - p0) : kTile;
-      for (uint32_t c = 0; c < cols; c += 4) {
-        float a[4];
-        block_multipliers<kMode>(k, lds_table, path_lo, path_hi, (p0 + c) >> 2, a);
+    float a_prev[4] = {100.0f, 100.0f, 100.0f, 100.0f}, a_cur[4] = {100.0f, 100.0f, 100.0f, 100.0f};
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+      const uint32_t g0 = t * kTile;
+#pragma unroll 2
+      for (uint32_t c = 0; c < kTile; c += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_prev[j] = a_cur[j];
+        block_multipliers<kMode>(k, lds_table, path_lo, path_hi, ((g0 + c) >> 2) - q, a_cur);
+        // m[j] = w[4 - rho + j] over w = {a_prev, a_cur}
+        float x2 = shift1 ? a_prev[1] : a_prev[2], x3 = shift1 ? a_prev[2] : a_prev[3];
+        float x4 = shift1 ? a_prev[3] : a_cur[0], x5 = shift1 ? a_cur[0] : a_cur[1];
+        float x6 = shift1 ? a_cur[1] : a_cur[2], x7 = shift1 ? a_cur[2] : a_cur[3];
+        const float m[4] = {shift2 ? x2 : x4, shift2 ? x3 : x5, shift2 ? x4 : x6, shift2 ? x5 : x7};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (c + j < cols) {  // wave-uniform
-            total = compound<kExactDiv>(total, a[j]);
-            tile[lane * kTilePad + c + j] = total;
-          }
+          const uint32_t period = g0 + c + j - psi;  // wraps below zero -> fails the test
+          const float next = compound<kExactDiv>(total, m[j]);
+          total = period < n_periods ? next : total;
+          tile[lane * kTilePad + c + j] = total;
         }
       }
       // The tile is private to this wave: order LDS writes before the row reads.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       {
-        float *dst = k.d_traj + (wave_first + sub_row) * row_len + 1 + p0 + col;
         const float *src = tile + sub_row * kTilePad + col;
-        const uint64_t dst_step = static_cast<uint64_t>(kRowsPerStore) * row_len;
+        uint64_t row_off = (wave_first + sub_row) * row_len;  // float offset of this lane's row in d_traj
+        const uint64_t row_step = static_cast<uint64_t>(kRowsPerStore) * row_len;
         constexpr int kUnroll = 4;
         uint32_t r = 0;
-        if (col < cols) {
-          for (; r + kUnroll * kRowsPerStore <= rows_here; r += kUnroll * kRowsPerStore) {
-            float v[kUnroll];
+        for (; r + kUnroll * kRowsPerStore <= rows_here; r += kUnroll * kRowsPerStore) {
+          float v[kUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) v[u] = src[(r + u * kRowsPerStore) * kTilePad];
+          for (int u = 0; u < kUnroll; ++u) v[u] = src[(r + u * kRowsPerStore) * kTilePad];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) dst[u * dst_step] = v[u];
-            dst += kUnroll * dst_step;
+          for (int u = 0; u < kUnroll; ++u) {
+            const uint32_t row_phi = static_cast<uint32_t>(base_f + row_off) & (kTile - 1);
+            const uint32_t s_idx = g0 + col - row_phi;  // value index; wraps below zero
+            if (s_idx <= n_periods) k.d_traj[row_off + s_idx] = v[u];
+            row_off += row_step;
           }
-          for (; r < rows_here; r += kRowsPerStore) {
-            if (r + sub_row < rows_here) *dst = src[r * kTilePad];
-            dst += dst_step;
-          }
+        }
+        for (; r < rows_here; r += kRowsPerStore) {
+          const uint32_t row_phi = static_cast<uint32_t>(base_f + row_off) & (kTile - 1);
+          const uint32_t s_idx = g0 + col - row_phi;
+          if (r + sub_row < rows_here && s_idx <= n_periods) k.d_traj[row_off + s_idx] = src[r * kTilePad];
+          row_off += row_step;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -555,7 +584,6 @@ static hipError_t launch_keepdata_mode(const KernelArgs &a, bool exact_div, int 
                                        hipStream_t stream) {
   const size_t lds = keepdata_lds_bytes(a.table_len, tile);
   switch (tile) {
-    case 16: return launch_keepdata_tile<kMode, 16>(a, exact_div, grid, lds, stream);
     case 32: return launch_keepdata_tile<kMode, 32>(a, exact_div, grid, lds, stream);
     case 64: return launch_keepdata_tile<kMode, 64>(a, exact_div, grid, lds, stream);
     default: return hipErrorInvalidValue;

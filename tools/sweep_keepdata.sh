@@ -1,5 +1,5 @@
 #!/bin/bash
-for T in 16 32 64; do for B in 4 8 16 64; do
+for T in 32 64; do for B in 2 4 8 16 64; do
   echo "tile=$T bpc=$B"; SMMC_KEEPDATA_TILE=$T SMMC_KEEPDATA_BLOCKS_PER_CU=$B python3 tools/bench_keepdata.py 2>/dev/null | python3 -c "
 import sys,json
 for l in sys.stdin:
