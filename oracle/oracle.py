@@ -80,6 +80,9 @@ def lib():
         L.orc_counter_mc.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats),
                                      C.c_void_p, C.c_int]
         L.orc_counter_path_returns.argtypes = [C.POINTER(Params), C.c_uint64, C.c_void_p]
+        L.orc_counter_path_indices.argtypes = [C.POINTER(Params), C.c_uint64, C.c_void_p]
+        L.orc_draws_per_block.restype = C.c_uint32
+        L.orc_draws_per_block.argtypes = [C.c_int32, C.c_uint32]
         L.orc_chunk_mean_var.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -187,6 +190,12 @@ def counter_mc(params, want_final=True, want_traj=False, n_threads=0):
 def counter_path_returns(params, path):
     out = np.empty(params.n_periods, dtype=np.float32)
     lib().orc_counter_path_returns(C.byref(params), C.c_uint64(path), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def counter_path_indices(params, path):
+    out = np.empty(params.n_periods, dtype=np.uint32)
+    lib().orc_counter_path_indices(C.byref(params), C.c_uint64(path), out.ctypes.data_as(C.c_void_p))
     return out
 
 

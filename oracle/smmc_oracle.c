@@ -26,9 +26,10 @@
  *       follows src/simulations.cpp:204-266 with deterministic per-path seeds
  *       (the reference seeds from std::random_device and has no seed argument).
  *       This is what bench.py times as the CPU baseline ("port").
- *   (C) "counter stream v1": Philox4x32-10 keyed by the 64-bit seed, counter =
- *       (global path id, step block, stream tag); table-indexed or Box-Muller
- *       Gaussian draws; the same three-rounding compounding step.  The HIP
+ *   (C) "counter stream v2": Philox4x32-10 keyed by the 64-bit seed, counter =
+ *       (global path id, step block, stream tag); table-indexed (eight draws per
+ *       block for tables <= 2048 entries) or Box-Muller Gaussian draws; the same
+ *       three-rounding compounding step.  The HIP
  *       kernels must reproduce this engine bit-for-bit (final values, histogram
  *       bucket counts, below-threshold counts).
  *
@@ -175,7 +176,7 @@ ORC_API int orc_ref_mc_simulations(int64_t n_paths, uint32_t n_periods, float in
 }
 
 /* ------------------------------------------------------------------------- */
-/* (C) counter stream v1                                                      */
+/* (C) counter stream v2                                                      */
 /* ------------------------------------------------------------------------- */
 
 /* Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy
@@ -296,20 +297,50 @@ typedef struct {
   float min, max;
 } orc_stats;
 
-/* The draws of one path, period by period, in percent (table mode: the table
- * entry; Gaussian mode: fma(std, z, mean)).  Exposed so tests can check the
- * draw stream itself. */
-static void path_returns_block(const orc_params *p, uint64_t path, uint32_t blk, float out[4],
-                               uint32_t idx_out[4]) {
+/* Table-draw schedule.  Tables of up to ORC_DENSE_MAX_TABLE entries take EIGHT indices
+ * from one Philox block ("dense"): each 64-bit half (u0:u1), (u2:u3) is a fraction x in
+ * [0,1); digit k = floor(T * frac(T^k * x)) for k = 0..2 by exact 64x32-bit multiplies,
+ * and the fourth digit from the top 32 bits of what is left.  Relative bias of digit k is
+ * below T^(k+1) / 2^64 (k < 3) and T^4/2^64 + T/2^32 (k = 3): < 1.3e-6 for T <= 2048.
+ * Larger tables take one index per 32-bit word ("sparse", four per block). */
+#define ORC_DENSE_MAX_TABLE 2048u
+
+ORC_API uint32_t orc_draws_per_block(int32_t mode, uint32_t table_len) {
+  return (mode == ORC_MODE_TABLE && table_len <= ORC_DENSE_MAX_TABLE) ? 8u : 4u;
+}
+
+static void digits4(uint32_t h, uint32_t l, uint32_t T, uint32_t idx[4]) {
+  for (int d = 0; d < 3; d++) {
+    uint64_t pl = (uint64_t)l * T;
+    uint64_t ph = (uint64_t)h * T + (pl >> 32);
+    idx[d] = (uint32_t)(ph >> 32);
+    h = (uint32_t)ph;
+    l = (uint32_t)pl;
+  }
+  idx[3] = (uint32_t)(((uint64_t)h * T) >> 32);
+}
+
+/* The draws of Philox block `blk` of one path, in percent (table mode: the table
+ * entry; Gaussian mode: fma(std, z, mean)): orc_draws_per_block() values.  Period p
+ * uses draw p % D of block p / D. */
+static void path_returns_block(const orc_params *p, uint64_t path, uint32_t blk, float out[8],
+                               uint32_t idx_out[8]) {
   uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), blk, (uint32_t)p->mode};
   uint32_t key[2] = {(uint32_t)p->seed, (uint32_t)(p->seed >> 32)};
   uint32_t u[4];
   orc_philox4x32_10(ctr, key, u);
   if (p->mode == ORC_MODE_TABLE) {
-    for (int j = 0; j < 4; j++) {
-      uint32_t idx = (uint32_t)(((uint64_t)u[j] * p->table_len) >> 32);
-      if (idx_out) idx_out[j] = idx;
-      out[j] = p->table[idx];
+    uint32_t idx[8];
+    uint32_t n = orc_draws_per_block(p->mode, p->table_len);
+    if (n == 8) {
+      digits4(u[0], u[1], p->table_len, idx);
+      digits4(u[2], u[3], p->table_len, idx + 4);
+    } else {
+      for (int j = 0; j < 4; j++) idx[j] = (uint32_t)(((uint64_t)u[j] * p->table_len) >> 32);
+    }
+    for (uint32_t j = 0; j < n; j++) {
+      if (idx_out) idx_out[j] = idx[j];
+      out[j] = p->table[idx[j]];
     }
   } else {
     float z[4];
@@ -321,20 +352,33 @@ static void path_returns_block(const orc_params *p, uint64_t path, uint32_t blk,
 
 /* Writes the n_periods returns of global path `path` (percent). */
 ORC_API void orc_counter_path_returns(const orc_params *p, uint64_t path, float *returns) {
-  for (uint32_t i = 0; i < p->n_periods; i += 4) {
-    float r[4];
-    path_returns_block(p, path, i / 4, r, 0);
-    for (uint32_t j = 0; j < 4 && i + j < p->n_periods; j++) returns[i + j] = r[j];
+  const uint32_t D = orc_draws_per_block(p->mode, p->table_len);
+  for (uint32_t i = 0; i < p->n_periods; i += D) {
+    float r[8];
+    path_returns_block(p, path, i / D, r, 0);
+    for (uint32_t j = 0; j < D && i + j < p->n_periods; j++) returns[i + j] = r[j];
+  }
+}
+
+/* Table indices drawn by a path (table mode), for distribution tests. */
+ORC_API void orc_counter_path_indices(const orc_params *p, uint64_t path, uint32_t *indices) {
+  const uint32_t D = orc_draws_per_block(p->mode, p->table_len);
+  for (uint32_t i = 0; i < p->n_periods; i += D) {
+    float r[8];
+    uint32_t idx[8];
+    path_returns_block(p, path, i / D, r, idx);
+    for (uint32_t j = 0; j < D && i + j < p->n_periods; j++) indices[i + j] = idx[j];
   }
 }
 
 static float counter_one_path(const orc_params *p, uint64_t path, float *trajectory) {
+  const uint32_t D = orc_draws_per_block(p->mode, p->table_len);
   float total = p->initial_capital;
   if (trajectory) trajectory[0] = total;
-  for (uint32_t i = 0; i < p->n_periods; i += 4) {
-    float r[4];
-    path_returns_block(p, path, i / 4, r, 0);
-    for (uint32_t j = 0; j < 4 && i + j < p->n_periods; j++) {
+  for (uint32_t i = 0; i < p->n_periods; i += D) {
+    float r[8];
+    path_returns_block(p, path, i / D, r, 0);
+    for (uint32_t j = 0; j < D && i + j < p->n_periods; j++) {
       total = orc_update_fund(total, r[j]);
       if (trajectory) trajectory[i + j + 1] = total;
     }

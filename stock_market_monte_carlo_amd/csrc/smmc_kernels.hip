@@ -23,6 +23,7 @@ constexpr uint32_t kPhiloxM0 = 0xD2511F53u;
 constexpr uint32_t kPhiloxM1 = 0xCD9E8D57u;
 constexpr uint32_t kWeyl0 = 0x9E3779B9u;
 constexpr uint32_t kWeyl1 = 0xBB67AE85u;
+constexpr uint32_t kDenseMaxTable = 2048u;  // largest table drawn eight-per-block
 
 // a ^ b ^ c in one VALU instruction (gfx950 v_bitop3_b32, truth table 0x96); hipcc
 // does not form it from two chained XORs on its own.
@@ -150,14 +151,44 @@ __device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float &z_co
   z_sin = r * __uint_as_float(__float_as_uint(sb) ^ sign_s);
 }
 
-// The four per-period multipliers a = 100.0f + r of Philox block `blk` of a path.
-template <int kMode>
+// Draws per Philox block: 8 for table mode with T <= 2048 ("dense"), else 4.
+template <int kMode, bool kDense>
+struct Draws {
+  static constexpr int value = (kMode == SMMC_MODE_TABLE && kDense) ? 8 : 4;
+};
+
+// Four base-T digits of the 64-bit fraction (h:l): digit k = floor(T * frac(T^k x)) by
+// exact 64 x 32-bit multiplies (two v_mad_u64_u32 each) for k = 0..2, the last one from
+// the top 32 bits of what is left.  Relative bias < T^4/2^64 + T/2^32 (< 1.3e-6, T <= 2048).
+__device__ __forceinline__ void digits4(uint32_t h, uint32_t l, uint32_t T, uint32_t (&idx)[4]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const uint64_t pl = static_cast<uint64_t>(l) * T;
+    const uint64_t ph = static_cast<uint64_t>(h) * T + (pl >> 32);
+    idx[d] = static_cast<uint32_t>(ph >> 32);
+    h = static_cast<uint32_t>(ph);
+    l = static_cast<uint32_t>(pl);
+  }
+  idx[3] = __umulhi(h, T);
+}
+
+// The per-period multipliers a = 100.0f + r of Philox block `blk` of a path.
+template <int kMode, bool kDense>
 __device__ __forceinline__ void block_multipliers(const KernelArgs &k, const float *lds_table,
                                                   uint32_t path_lo, uint32_t path_hi, uint32_t blk,
-                                                  float (&a)[4]) {
+                                                  float (&a)[Draws<kMode, kDense>::value]) {
   uint32_t u[4];
   philox4x32_10(path_lo, path_hi, blk, static_cast<uint32_t>(kMode), k.key0, k.key1, u);
-  if constexpr (kMode == SMMC_MODE_TABLE) {
+  if constexpr (kMode == SMMC_MODE_TABLE && kDense) {
+    uint32_t ia[4], ib[4];
+    digits4(u[0], u[1], k.table_len, ia);
+    digits4(u[2], u[3], k.table_len, ib);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] = lds_table[ia[j]];
+      a[4 + j] = lds_table[ib[j]];
+    }
+  } else if constexpr (kMode == SMMC_MODE_TABLE) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[j] = lds_table[__umulhi(u[j], k.table_len)];
   } else {
@@ -169,26 +200,27 @@ __device__ __forceinline__ void block_multipliers(const KernelArgs &k, const flo
   }
 }
 
-template <int kMode, bool kExactDiv>
+template <int kMode, bool kExactDiv, bool kDense>
 __device__ __forceinline__ float simulate_path(const KernelArgs &k, const float *lds_table,
                                                uint64_t path) {
+  constexpr int kDraws = Draws<kMode, kDense>::value;
   const uint32_t path_lo = static_cast<uint32_t>(path);
   const uint32_t path_hi = static_cast<uint32_t>(path >> 32);
   float total = k.initial_capital;
-  const uint32_t full = k.n_periods >> 2;
+  const uint32_t full = k.n_periods / kDraws;
   for (uint32_t blk = 0; blk < full; ++blk) {
-    float a[4];
-    block_multipliers<kMode>(k, lds_table, path_lo, path_hi, blk, a);
+    float a[kDraws];
+    block_multipliers<kMode, kDense>(k, lds_table, path_lo, path_hi, blk, a);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) total = compound<kExactDiv>(total, a[j]);
+    for (int j = 0; j < kDraws; ++j) total = compound<kExactDiv>(total, a[j]);
   }
-  const uint32_t rem = k.n_periods & 3u;
-  if (rem) {
-    float a[4];
-    block_multipliers<kMode>(k, lds_table, path_lo, path_hi, full, a);
-    total = compound<kExactDiv>(total, a[0]);
-    if (rem > 1) total = compound<kExactDiv>(total, a[1]);
-    if (rem > 2) total = compound<kExactDiv>(total, a[2]);
+  const uint32_t rem = k.n_periods - full * kDraws;
+  if (rem) {  // wave-uniform
+    float a[kDraws];
+    block_multipliers<kMode, kDense>(k, lds_table, path_lo, path_hi, full, a);
+#pragma unroll
+    for (int j = 0; j < kDraws - 1; ++j)
+      if (static_cast<uint32_t>(j) < rem) total = compound<kExactDiv>(total, a[j]);
   }
   return total;
 }
@@ -237,7 +269,7 @@ __device__ __forceinline__ double block_sum_bcast(double v, double *scratch /* k
 // Persistent workgroups; each iteration one chunk of 256 consecutive paths (one
 // per lane) so the final-value store of a wave is one 256-byte line-aligned
 // segment.  LDS: [table (100 + r)] [histogram u32 bins].
-template <int kMode, bool kExactDiv>
+template <int kMode, bool kExactDiv, bool kDense>
 __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float *lds_table = reinterpret_cast<float *>(lds_raw);
@@ -267,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
     const bool active = i < k.n_paths;
     float v = 0.0f;
     if (active) {
-      v = simulate_path<kMode, kExactDiv>(k, lds_table, k.first_path + i);
+      v = simulate_path<kMode, kExactDiv, kDense>(k, lds_table, k.first_path + i);
       if (k.d_final) k.d_final[i] = v;
     }
     if (want_stats && active) {
@@ -413,12 +445,14 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const BlockPartial *pa
 // the moment they are written.  Only the first and last window of a row are partial.
 //
 // Column g of lane r holds value index s = g - phi_r (0 = initial capital, s >= 1 =
-// after period s - 1).  Philox blocks stay wave-uniform in time: at column group G
-// every lane draws block G - q_r, and a two-stage barrel shifter over the previous and
-// current block's multipliers applies the lane's residual shift rho_r in {0,1,2,3}
-// (phi_r + 1 = 4 q_r + rho_r).  Lanes idle (keep their value) outside 1 <= s <= P.
-template <int kMode, bool kExactDiv, int kTile>
+// after period s - 1).  Philox blocks stay wave-uniform in time: with D draws per
+// block, at column group G every lane draws block G - q_r, and a log2(D)-stage barrel
+// shifter over the previous and current block's multipliers applies the lane's
+// residual shift rho_r in [0, D) (phi_r + 1 = D q_r + rho_r).  Lanes idle (keep their
+// value) outside 1 <= s <= P.
+template <int kMode, bool kExactDiv, bool kDense, int kTile>
 __global__ __launch_bounds__(kBlock) void keepdata_kernel(const KernelArgs k) {
+  constexpr int kDraws = Draws<kMode, kDense>::value;
   constexpr int kTilePad = kTile + 1;        // +1 word: column writes and row reads conflict-free
   constexpr int kRowsPerStore = 64 / kTile;  // rows covered by one wave-wide store
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -449,28 +483,38 @@ __global__ __launch_bounds__(kBlock) void keepdata_kernel(const KernelArgs k) {
     const uint32_t path_lo = static_cast<uint32_t>(path), path_hi = static_cast<uint32_t>(path >> 32);
 
     const uint32_t phi = static_cast<uint32_t>(base_f + i * row_len) & (kTile - 1);
-    const uint32_t psi = phi + 1;  // period = column - psi
-    const uint32_t q = psi >> 2;
-    const bool shift1 = (psi & 1u) != 0, shift2 = (psi & 2u) != 0;
+    const uint32_t psi = phi + 1;           // period = column - psi
+    const uint32_t q = psi / kDraws;        // whole blocks of delay
+    const uint32_t rho = psi % kDraws;      // residual shift inside a block
 
     float total = k.initial_capital;
-    float a_prev[4] = {100.0f, 100.0f, 100.0f, 100.0f}, a_cur[4] = {100.0f, 100.0f, 100.0f, 100.0f};
+    float w[2 * kDraws];  // previous block's multipliers, then the current block's
+#pragma unroll
+    for (int j = 0; j < 2 * kDraws; ++j) w[j] = 100.0f;
     for (uint32_t t = 0; t < n_tiles; ++t) {
       const uint32_t g0 = t * kTile;
-#pragma unroll 2
-      for (uint32_t c = 0; c < kTile; c += 4) {
+      for (uint32_t c = 0; c < kTile; c += kDraws) {
+        float cur[kDraws];
+        block_multipliers<kMode, kDense>(k, lds_table, path_lo, path_hi, (g0 + c) / kDraws - q, cur);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a_prev[j] = a_cur[j];
-        block_multipliers<kMode>(k, lds_table, path_lo, path_hi, ((g0 + c) >> 2) - q, a_cur);
-        // m[j] = w[4 - rho + j] over w = {a_prev, a_cur}
-        float x2 = shift1 ? a_prev[1] : a_prev[2], x3 = shift1 ? a_prev[2] : a_prev[3];
-        float x4 = shift1 ? a_prev[3] : a_cur[0], x5 = shift1 ? a_cur[0] : a_cur[1];
-        float x6 = shift1 ? a_cur[1] : a_cur[2], x7 = shift1 ? a_cur[2] : a_cur[3];
-        const float m[4] = {shift2 ? x2 : x4, shift2 ? x3 : x5, shift2 ? x4 : x6, shift2 ? x5 : x7};
+        for (int j = 0; j < kDraws; ++j) {
+          w[j] = w[kDraws + j];
+          w[kDraws + j] = cur[j];
+        }
+        // barrel shifter: m[j] = w[kDraws - rho + j], one stage per bit of rho
+        float x[2 * kDraws];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2 * kDraws; ++j) x[j] = w[j];
+#pragma unroll
+        for (int sh = 1; sh < kDraws; sh <<= 1) {
+          const bool on = (rho & sh) != 0;
+#pragma unroll
+          for (int j = 2 * kDraws - 1; j >= sh; --j) x[j] = on ? x[j - sh] : x[j];
+        }
+#pragma unroll
+        for (int j = 0; j < kDraws; ++j) {
           const uint32_t period = g0 + c + j - psi;  // wraps below zero -> fails the test
-          const float next = compound<kExactDiv>(total, m[j]);
+          const float next = compound<kExactDiv>(total, x[kDraws + j]);
           total = period < n_periods ? next : total;
           tile[lane * kTilePad + c + j] = total;
         }
@@ -546,20 +590,23 @@ size_t keepdata_lds_bytes(uint32_t table_len, int tile) {
   return (static_cast<size_t>(table_len) + static_cast<size_t>(kWaves) * 64 * (tile + 1)) * 4u;
 }
 
-template <int kMode>
+template <int kMode, bool kDense>
 static hipError_t launch_paths_mode(const KernelArgs &a, bool exact_div, uint32_t grid, size_t lds,
                                     hipStream_t stream) {
   if (exact_div)
-    hipLaunchKernelGGL((paths_kernel<kMode, true>), dim3(grid), dim3(kBlock), lds, stream, a);
+    hipLaunchKernelGGL((paths_kernel<kMode, true, kDense>), dim3(grid), dim3(kBlock), lds, stream, a);
   else
-    hipLaunchKernelGGL((paths_kernel<kMode, false>), dim3(grid), dim3(kBlock), lds, stream, a);
+    hipLaunchKernelGGL((paths_kernel<kMode, false, kDense>), dim3(grid), dim3(kBlock), lds, stream, a);
   return hipGetLastError();
 }
 
+bool table_is_dense(uint32_t table_len) { return table_len <= kDenseMaxTable; }
+
 hipError_t launch_paths(const KernelArgs &a, bool exact_div, uint32_t grid, size_t lds_bytes,
                         hipStream_t stream) {
-  return a.mode == SMMC_MODE_TABLE ? launch_paths_mode<SMMC_MODE_TABLE>(a, exact_div, grid, lds_bytes, stream)
-                   : launch_paths_mode<SMMC_MODE_GAUSSIAN>(a, exact_div, grid, lds_bytes, stream);
+  if (a.mode != SMMC_MODE_TABLE) return launch_paths_mode<SMMC_MODE_GAUSSIAN, false>(a, exact_div, grid, lds_bytes, stream);
+  return table_is_dense(a.table_len) ? launch_paths_mode<SMMC_MODE_TABLE, true>(a, exact_div, grid, lds_bytes, stream)
+                                     : launch_paths_mode<SMMC_MODE_TABLE, false>(a, exact_div, grid, lds_bytes, stream);
 }
 
 hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, smmc_stats *d_stats,
@@ -569,30 +616,31 @@ hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, sm
   return hipGetLastError();
 }
 
-template <int kMode, int kTile>
+template <int kMode, bool kDense, int kTile>
 static hipError_t launch_keepdata_tile(const KernelArgs &a, bool exact_div, uint32_t grid, size_t lds,
                                        hipStream_t stream) {
   if (exact_div)
-    hipLaunchKernelGGL((keepdata_kernel<kMode, true, kTile>), dim3(grid), dim3(kBlock), lds, stream, a);
+    hipLaunchKernelGGL((keepdata_kernel<kMode, true, kDense, kTile>), dim3(grid), dim3(kBlock), lds, stream, a);
   else
-    hipLaunchKernelGGL((keepdata_kernel<kMode, false, kTile>), dim3(grid), dim3(kBlock), lds, stream, a);
+    hipLaunchKernelGGL((keepdata_kernel<kMode, false, kDense, kTile>), dim3(grid), dim3(kBlock), lds, stream, a);
   return hipGetLastError();
 }
 
-template <int kMode>
+template <int kMode, bool kDense>
 static hipError_t launch_keepdata_mode(const KernelArgs &a, bool exact_div, int tile, uint32_t grid,
                                        hipStream_t stream) {
   const size_t lds = keepdata_lds_bytes(a.table_len, tile);
   switch (tile) {
-    case 32: return launch_keepdata_tile<kMode, 32>(a, exact_div, grid, lds, stream);
-    case 64: return launch_keepdata_tile<kMode, 64>(a, exact_div, grid, lds, stream);
+    case 32: return launch_keepdata_tile<kMode, kDense, 32>(a, exact_div, grid, lds, stream);
+    case 64: return launch_keepdata_tile<kMode, kDense, 64>(a, exact_div, grid, lds, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
 hipError_t launch_keepdata(const KernelArgs &a, bool exact_div, int tile, uint32_t grid, hipStream_t stream) {
-  return a.mode == SMMC_MODE_TABLE ? launch_keepdata_mode<SMMC_MODE_TABLE>(a, exact_div, tile, grid, stream)
-                                   : launch_keepdata_mode<SMMC_MODE_GAUSSIAN>(a, exact_div, tile, grid, stream);
+  if (a.mode != SMMC_MODE_TABLE) return launch_keepdata_mode<SMMC_MODE_GAUSSIAN, false>(a, exact_div, tile, grid, stream);
+  return table_is_dense(a.table_len) ? launch_keepdata_mode<SMMC_MODE_TABLE, true>(a, exact_div, tile, grid, stream)
+                                     : launch_keepdata_mode<SMMC_MODE_TABLE, false>(a, exact_div, tile, grid, stream);
 }
 
 }  // namespace smmc

@@ -4,7 +4,7 @@
                           paths, produced by oracle/pin/pin_libstdcxx.cpp (the real
                           library the reference calls at src/simulations.cpp:245-250).
                           This pins the oracle's hand-written mt19937 / Lemire map.
-  counter_stream_v1.json  frozen outputs of the oracle's counter-stream engine (C):
+  counter_stream_v2.json  frozen outputs of the oracle's counter-stream engine (C):
                           regression vectors for the HIP kernels that also travel to
                           the GPU box.  These are pinned to the oracle itself only.
 
@@ -71,7 +71,7 @@ def main():
                     "below": int(st.below), "underflow": int(st.underflow), "overflow": int(st.overflow),
                     "sum": st.sum, "sumsq": st.sumsq, "min": float(st.min), "max": float(st.max),
                 })
-    with open(os.path.join(HERE, "counter_stream_v1.json"), "w") as f:
+    with open(os.path.join(HERE, "counter_stream_v2.json"), "w") as f:
         json.dump({"table_bits_fnv1a": int(fnv1a(table.view(np.uint32))), "cases": cases}, f)
     print("wrote fixtures")
 

@@ -45,7 +45,7 @@ def _run_both(eng, oracle, table, mode, n, p, first=0, seed=SEED, n_bins=0, lo=0
 
 
 @pytest.mark.parametrize("mode_name", ["table", "gaussian"])
-@pytest.mark.parametrize("p", [0, 1, 3, 4, 5, 7, 360, 1000])
+@pytest.mark.parametrize("p", [0, 1, 3, 4, 5, 7, 8, 9, 15, 360, 1000])
 def test_final_values_bit_exact(eng, oracle, table, mode_name, p):
     mode = _modes()[mode_name]
     n = 5000 + 37  # ragged: not a multiple of 256
@@ -74,9 +74,9 @@ def test_path_ids_beyond_32_bits_and_seed_halves(eng, oracle, table, mode_name):
 
 
 def test_golden_counter_stream(eng, table):
-    """Frozen oracle outputs (tests/golden/counter_stream_v1.json, made by make_golden.py)."""
+    """Frozen oracle outputs (tests/golden/counter_stream_v2.json, made by make_golden.py)."""
     from stock_market_monte_carlo_amd import Engine
-    with open(os.path.join(HERE, "golden", "counter_stream_v1.json")) as f:
+    with open(os.path.join(HERE, "golden", "counter_stream_v2.json")) as f:
         gold = json.load(f)
     for c in gold["cases"]:
         sim = Engine.make_sim(c["n_paths"], c["n_periods"], _modes()[c["mode"]], c["seed"], first_path=c["first_path"],
@@ -157,6 +157,26 @@ def test_empty_and_tiny(eng, table):
     assert r.final.cpu().numpy().tolist() == [123.5]
 
 
+def test_large_table_uses_the_sparse_schedule(eng, oracle):
+    """> 2048 entries: four draws per Philox block (the dense digit extraction would bias)."""
+    from stock_market_monte_carlo_amd import Engine, MODE_TABLE
+    from conftest import load_table
+    rng = np.random.default_rng(11)
+    big = rng.normal(0.05, 1.1, 5000).astype(np.float32)
+    eng.set_table(big)
+    try:
+        for p in (1, 7, 8, 250):
+            r, st, o = _run_both(eng, oracle, big, MODE_TABLE, 3001, p, n_bins=20, lo=0.0, hi=3000.0)
+            assert np.array_equal(r.final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32)), p
+            assert np.array_equal(st.hist, o["hist"])
+        sim = Engine.make_sim(200, 70, MODE_TABLE, SEED, first_path=5)
+        traj, _ = eng.simulate_keepdata(sim)
+        o = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 70, 200, SEED, first_path=5, table=big), want_traj=True)
+        assert np.array_equal(traj.cpu().numpy().view(np.uint32), o["traj"].view(np.uint32))
+    finally:
+        eng.set_table(load_table())
+
+
 def test_table_of_one_entry_is_deterministic_compounding(eng, oracle):
     from stock_market_monte_carlo_amd import Engine, MODE_TABLE
     from conftest import load_table
@@ -173,7 +193,7 @@ def test_table_of_one_entry_is_deterministic_compounding(eng, oracle):
 def test_keepdata_trajectories_bit_exact(eng, oracle, table, mode_name):
     from stock_market_monte_carlo_amd import Engine
     mode = _modes()[mode_name]
-    for n, p in [(300, 360), (1000, 1), (257, 64), (64, 65), (700, 130)]:
+    for n, p in [(300, 360), (1000, 1), (257, 64), (64, 65), (700, 130), (130, 31), (65, 7), (1, 100)]:
         sim = Engine.make_sim(n, p, mode, SEED, first_path=11)
         traj, final = eng.simulate_keepdata(sim)
         op = oracle.make_params(mode, p, n, SEED, first_path=11, table=table)

@@ -56,3 +56,54 @@ def test_histogram_bucket_contract(oracle):
     assert L.orc_hist_bucket(100.0, 0.0, 100.0, 10) == 10
     assert L.orc_hist_bucket(float("nan"), 0.0, 100.0, 10) == 10
     assert L.orc_hist_bucket(float("inf"), 0.0, 100.0, 10) == 10
+
+
+def test_dense_table_digits_match_big_integer_arithmetic(oracle, table):
+    """Stream v2, tables <= 2048 entries: eight indices per Philox block by base-T digit
+    extraction from the two 64-bit halves.  Checked against exact Python integers."""
+    seed = 0xABCDEF0123456789
+    for T in (1127, 1, 2, 2048, 1000):
+        tab = np.arange(T, dtype=np.float32)  # entry value == index
+        p = oracle.make_params(oracle.MODE_TABLE, 24, 1, seed, table=tab)
+        for path in (0, 5, (1 << 33) + 17):
+            got = oracle.counter_path_indices(p, path)
+            want = []
+            for blk in range(3):
+                u = [int(x) for x in oracle.philox4x32_10([path & 0xFFFFFFFF, path >> 32, blk, 0],
+                                                          [seed & 0xFFFFFFFF, seed >> 32])]
+                for hi, lo in ((u[0], u[1]), (u[2], u[3])):
+                    x = (hi << 32) | lo
+                    for _ in range(3):
+                        prod = x * T
+                        want.append(prod >> 64)
+                        x = prod & ((1 << 64) - 1)
+                    want.append(((x >> 32) * T) >> 32)
+            assert [int(v) for v in got] == want, (T, path)
+            # and the draws are the table entries at those indices
+            assert np.array_equal(oracle.counter_path_returns(p, path), tab[got])
+
+
+def test_sparse_schedule_for_large_tables(oracle):
+    """Tables above 2048 entries: one index per 32-bit word, (u * T) >> 32."""
+    T, seed = 5000, 99
+    tab = np.arange(T, dtype=np.float32)
+    p = oracle.make_params(oracle.MODE_TABLE, 8, 1, seed, table=tab)
+    got = oracle.counter_path_indices(p, 3)
+    want = []
+    for blk in range(2):
+        u = oracle.philox4x32_10([3, 0, blk, 0], [seed, 0])
+        want += [(int(x) * T) >> 32 for x in u]
+    assert [int(v) for v in got] == want
+    assert oracle.lib().orc_draws_per_block(oracle.MODE_TABLE, 2048) == 8
+    assert oracle.lib().orc_draws_per_block(oracle.MODE_TABLE, 2049) == 4
+    assert oracle.lib().orc_draws_per_block(oracle.MODE_GAUSSIAN, 10) == 4
+
+
+def test_dense_draws_are_uniform(oracle, table):
+    p = oracle.make_params(oracle.MODE_TABLE, 4000, 1, 77, table=table)
+    cnt = np.zeros(table.size)
+    for path in range(300):
+        cnt += np.bincount(oracle.counter_path_indices(p, path), minlength=table.size)
+    e = cnt.sum() / table.size
+    chi = ((cnt - e) ** 2 / e).sum()
+    assert abs(chi - (table.size - 1)) < 5 * np.sqrt(2 * (table.size - 1))
