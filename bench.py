@@ -38,9 +38,9 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock = 7.86e13 lane-ops/s
 # VALU work per path-period of paths_kernel's inner loop, from the gfx950 ISA
 # (tools/isa_loop_count.py): instructions, and issue units where a
-# plain VALU op = 1 and multi-cycle ones carry their measured cost (mad_u64 2.05, ...)
-VALU_INSTS_PER_STEP = {"gaussian": 159 / 4, "table": 62 / 4}
-VALU_UNITS_PER_STEP = {"gaussian": 51.1, "table": 21.6}
+# plain VALU op = 1 and multi-cycle ones carry their measured cost (mad_u64 2.29, ...)
+VALU_INSTS_PER_STEP = {"gaussian": 131 / 4, "table": 96 / 8}
+VALU_UNITS_PER_STEP = {"gaussian": 40.1, "table": 17.7}
 
 
 def load_table():

@@ -178,12 +178,10 @@ int smmc_engine_simulate_keepdata_to_host(smmc_engine *e, const smmc_sim *sim, f
 int smmc_engine_timing(smmc_engine *e, int enable);
 int smmc_engine_kernel_ms(smmc_engine *e, double *total_ms, uint32_t *launches);
 
-/* Device self-test of the kernels' two arithmetic shortcuts over the binary32 bit
- * patterns [bits_lo, bits_hi): div_mismatches counts x where the reciprocal-multiply
- * divide differs from the IEEE x / 100.0f, sqrt_mismatches where the fixed-up
- * v_sqrt_f32 differs from the IEEE sqrtf(x).  Synchronous. */
-int smmc_engine_selftest(smmc_engine *e, uint32_t bits_lo, uint32_t bits_hi, uint64_t *div_mismatches,
-                         uint64_t *sqrt_mismatches);
+/* Device self-test of the kernels' divide shortcut over the binary32 bit patterns
+ * [bits_lo, bits_hi): counts x where the reciprocal-multiply divide differs from the
+ * IEEE x / 100.0f.  Synchronous. */
+int smmc_engine_selftest(smmc_engine *e, uint32_t bits_lo, uint32_t bits_hi, uint64_t *div_mismatches);
 
 /* Launch geometry the engine will use (workgroups x threads), for reports. */
 int smmc_engine_geometry(smmc_engine *e, uint32_t *grid, uint32_t *block, uint32_t *compute_units);

@@ -49,8 +49,8 @@ class Stats(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "smmc_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "smmc_oracle.c"), os.path.join(_HERE, "smmc_bm_tables.inc")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libsmmc_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -65,14 +65,14 @@ def lib():
         L = C.CDLL(_SO)
         L.orc_update_fund.restype = C.c_float
         L.orc_update_fund.argtypes = [C.c_float, C.c_float]
-        L.orc_log_kernel.restype = C.c_float
-        L.orc_log_kernel.argtypes = [C.c_float]
+        L.orc_bm_radius.restype = C.c_float
+        L.orc_bm_radius.argtypes = [C.c_uint32]
+        L.orc_bm_radius_scan.restype = C.c_double
+        L.orc_bm_radius_scan.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_hist_bucket.restype = C.c_int32
         L.orc_hist_bucket.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32]
         L.orc_div100_mismatches.restype = C.c_uint64
         L.orc_div100_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
-        L.orc_log_kernel_scan.restype = C.c_uint64
-        L.orc_log_kernel_scan.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
         L.orc_ref_mc_simulations.restype = C.c_int
         L.orc_ref_mc_simulations.argtypes = [C.c_int64, C.c_uint32, C.c_float, C.c_void_p, C.c_uint32,
                                              C.c_uint32, C.c_void_p, C.c_int]
@@ -215,7 +215,9 @@ def div100_mismatches(bits_lo, bits_hi):
     return int(n), first.value
 
 
-def log_kernel_scan(bits_lo, bits_hi):
-    worst = C.c_double(0)
-    n = lib().orc_log_kernel_scan(C.c_uint32(bits_lo), C.c_uint32(bits_hi), C.byref(worst))
-    return int(n), worst.value
+def bm_radius(ua):
+    return float(lib().orc_bm_radius(C.c_uint32(ua)))
+
+
+def bm_radius_scan(lo, hi, stride):
+    return float(lib().orc_bm_radius_scan(C.c_uint64(lo), C.c_uint64(hi), C.c_uint64(stride)))

@@ -204,69 +204,42 @@ ORC_API void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uin
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-/* ln(x) for normal positive binary32 x, Cephes-style degree-8 kernel on
- * [sqrt(1/2), sqrt(2)); every operation is a single rounded binary32 op. */
-ORC_API float orc_log_kernel(float x) {
-  uint32_t ix = f2u(x);
-  ix += 0x3f800000u - 0x3f3504f3u;
-  int32_t e = (int32_t)(ix >> 23) - 127;
-  ix = (ix & 0x007fffffu) + 0x3f3504f3u;
-  float f = u2f(ix) - 1.0f;
-  float fe = (float)e;
-  float z = f * f;
-  float p = 7.0376836292E-2f;
-  p = fmaf(p, f, -1.1514610310E-1f);
-  p = fmaf(p, f, 1.1676998740E-1f);
-  p = fmaf(p, f, -1.2420140846E-1f);
-  p = fmaf(p, f, 1.4249322787E-1f);
-  p = fmaf(p, f, -1.6668057665E-1f);
-  p = fmaf(p, f, 2.0000714765E-1f);
-  p = fmaf(p, f, -2.4999993993E-1f);
-  p = fmaf(p, f, 3.3333331174E-1f);
-  float fz = f * z;
-  float y = fz * p;
-  y = fmaf(fe, -2.12194440e-4f, y);
-  y = fmaf(-0.5f, z, y);
-  float r = f + y;
-  r = fmaf(fe, 0.693359375f, r);
-  return r;
+/* Box-Muller tables of counter stream v2 (generated by tools/gen_bm_tables.py; the HIP
+ * kernels compile the identical numbers). */
+#include "smmc_bm_tables.inc"
+
+/* Radius r = sqrt(-2 ln U), U = (2 ua + 1) / 2^33, without log or sqrt: U is binned
+ * geometrically from the end it is nearer to (side 0: U < 1/2 by U, side 1: by 1 - U),
+ * 32 octaves x 16 sub-intervals per side, one cubic per bin in x in [-0.5, 0.5).
+ * Integer steps, then three fmaf: bit-reproducible on any IEEE machine. */
+ORC_API float orc_bm_radius(uint32_t ua) {
+  uint32_t mask = (uint32_t)((int32_t)ua >> 31); /* all ones when U >= 1/2 */
+  uint32_t w = ua ^ mask;                        /* distance from the nearer end, < 2^31 */
+  uint32_t w1 = (w << 1) | 1u;                   /* 2 w + 1: odd, in [1, 2^32) */
+  uint32_t c = (uint32_t)__builtin_clz(w1);      /* octave */
+  uint32_t m = w1 << c;                          /* normalised: bit 31 set */
+  uint32_t entry = (mask & 512u) + (c << 4) + ((m >> 27) & 15u);
+  float x = u2f(0x3f800000u | ((m >> 4) & 0x007fffffu)) - 1.5f;
+  const float *k = smmc_bm_radius[entry];
+  return fmaf(fmaf(fmaf(k[3], x, k[2]), x, k[1]), x, k[0]);
 }
 
-/* Box-Muller on two 32-bit words: ua -> radius, ub -> angle.
- *   U1    = fma((float)ua, 2^-32, 2^-33)          in (0, 1]
- *   r     = sqrtf(-2 * log_kernel(U1))            (IEEE sqrt)
- *   v     = ub + 2^29 (mod 2^32); q = v >> 30; g = (v & (2^30-1)) - 2^29
- *   theta = 2*pi*ub/2^32 = q*pi/2 + alpha, alpha = (float)g * fl(pi * 2^-31)
- *   sin/cos(alpha) from degree-7/8 kernels on [-pi/4, pi/4), then the quadrant
- *   rotation by sign-bit XOR and a swap.
+/* Box-Muller on two 32-bit words: ua -> radius (above), ub -> angle theta = 2 pi ub / 2^32
+ * = 2 pi i / 256 + delta with i = (ub + 2^23) >> 24 and delta = sext24(ub) * 2 pi / 2^32,
+ * |delta| <= pi/256: (cos, sin)(2 pi i / 256) from the table, rotated by
+ * sin(delta) = delta (1 - delta^2/6), cos(delta) = 1 - delta^2/2 (errors < 1e-9).
  *   z_cos = r * cos(theta), z_sin = r * sin(theta). */
 ORC_API void orc_box_muller(uint32_t ua, uint32_t ub, float *z_cos, float *z_sin) {
-  float u1 = fmaf((float)ua, 0x1p-32f, 0x1p-33f);
-  float l = orc_log_kernel(u1);
-  float t = -2.0f * l;
-  float r = sqrtf(t);
-
-  uint32_t v = ub + 0x20000000u;
-  int32_t g = (int32_t)(v & 0x3fffffffu) - 0x20000000;
-  float a = (float)g * 0x1.921fb6p-30f;
-  float z = a * a;
-  float ps = fmaf(-1.9515295891E-4f, z, 8.3321608736E-3f);
-  ps = fmaf(ps, z, -1.6666654611E-1f);
-  float az = a * z;
-  float s = fmaf(az, ps, a);
-  float pc = fmaf(2.443315711809948E-5f, z, -1.388731625493765E-3f);
-  pc = fmaf(pc, z, 4.166664568298827E-2f);
-  float zz = z * z;
-  float h = fmaf(-0.5f, z, 1.0f);
-  float c = fmaf(zz, pc, h);
-
-  uint32_t swap = v & 0x40000000u;
-  uint32_t sign_s = v & 0x80000000u;
-  uint32_t sign_c = (v + 0x40000000u) & 0x80000000u;
-  float cb = swap ? s : c;
-  float sb = swap ? c : s;
-  float ct = u2f(f2u(cb) ^ sign_c);
-  float st = u2f(f2u(sb) ^ sign_s);
+  float r = orc_bm_radius(ua);
+  uint32_t i = (ub + 0x00800000u) >> 24;
+  int32_t d = (int32_t)(ub << 8) >> 8; /* low 24 bits, sign-extended */
+  float delta = (float)d * 0x1.921fb6p-30f;
+  float d2 = delta * delta;
+  float sd = delta * fmaf(d2, -0x1.555556p-3f, 1.0f);
+  float cd = fmaf(d2, -0.5f, 1.0f);
+  float ci = smmc_bm_trig[i][0], si = smmc_bm_trig[i][1];
+  float ct = fmaf(-si, sd, ci * cd);
+  float st = fmaf(ci, sd, si * cd);
   *z_cos = r * ct;
   *z_sin = r * st;
 }
@@ -493,22 +466,15 @@ ORC_API uint64_t orc_div100_mismatches(uint32_t bits_lo, uint32_t bits_hi, uint3
   return bad;
 }
 
-/* Scans binary32 patterns of U1 in [bits_lo, bits_hi): returns how many give a
- * positive log_kernel (which would make the Box-Muller radius NaN) and the
- * largest relative error against the double-precision log. */
-ORC_API uint64_t orc_log_kernel_scan(uint32_t bits_lo, uint32_t bits_hi, double *max_rel_err) {
-  uint64_t positive = 0;
+/* Scans ua = lo, lo + stride, ... < hi: largest absolute error of orc_bm_radius against
+ * sqrt(-2 ln((2 ua + 1) / 2^33)) in double precision. */
+ORC_API double orc_bm_radius_scan(uint64_t lo, uint64_t hi, uint64_t stride) {
   double worst = 0;
-  for (uint64_t b = bits_lo; b < bits_hi; b++) {
-    float x = u2f((uint32_t)b);
-    float l = orc_log_kernel(x);
-    if (l > 0.0f) positive++;
-    double ref = log((double)x);
-    if (ref != 0.0) {
-      double rel = fabs(((double)l - ref) / ref);
-      if (rel > worst) worst = rel;
-    }
+  for (uint64_t a = lo; a < hi; a += stride) {
+    double u = (2.0 * (double)a + 1.0) * 0x1p-33;
+    double ref = a < 0x80000000ull ? sqrt(-2.0 * log(u)) : sqrt(-2.0 * log1p(-(2.0 * (double)(0xFFFFFFFFull - a) + 1.0) * 0x1p-33));
+    double err = fabs((double)orc_bm_radius((uint32_t)a) - ref);
+    if (err > worst) worst = err;
   }
-  if (max_rel_err) *max_rel_err = worst;
-  return positive;
+  return worst;
 }

@@ -21,6 +21,8 @@
 
 namespace {
 
+#include "smmc_bm_tables.inc"  // smmc_bm_radius[1024][4], smmc_bm_trig[256][2]
+
 thread_local char g_err[512] = "";
 
 int fail(int code, const char *fmt, ...) {
@@ -76,6 +78,7 @@ struct smmc_engine {
   float table_min_a = 0.f, table_max_a = 0.f;
   bool table_finite = false;
 
+  float *d_bm_tables = nullptr;  // Box-Muller radius + trig tables (Gaussian mode)
   smmc::BlockPartial *d_partials = nullptr;  // max_grid entries
 
   // simulate_to_host staging
@@ -147,6 +150,7 @@ smmc::KernelArgs make_args(const smmc_engine *e, const smmc_sim *s) {
   a.mode = s->mode;
   a.table_a = s->mode == SMMC_MODE_TABLE ? e->d_table : nullptr;
   a.table_len = s->mode == SMMC_MODE_TABLE ? e->table_len : 0u;
+  a.bm_tables = e->d_bm_tables;
   a.key0 = static_cast<uint32_t>(s->seed);
   a.key1 = static_cast<uint32_t>(s->seed >> 32);
   a.first_path = s->first_path;
@@ -293,6 +297,22 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     smmc_engine_destroy(e);
     return fail(SMMC_ERR_HIP, "hipMalloc(partials) failed: %s", hipGetErrorString(err));
   }
+  // Box-Muller tables: radius cubics then (cos, sin) pairs, as the kernels stage them
+  static_assert(sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig) == 18432, "table layout");
+  if (smmc::bm_tables_bytes() != sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig)) {
+    smmc_engine_destroy(e);
+    return fail(SMMC_ERR_INVALID, "Box-Muller table size mismatch between host and kernels");
+  }
+  err = hipMalloc(reinterpret_cast<void **>(&e->d_bm_tables), smmc::bm_tables_bytes());
+  if (err == hipSuccess)
+    err = hipMemcpy(e->d_bm_tables, smmc_bm_radius, sizeof(smmc_bm_radius), hipMemcpyHostToDevice);
+  if (err == hipSuccess)
+    err = hipMemcpy(reinterpret_cast<char *>(e->d_bm_tables) + sizeof(smmc_bm_radius), smmc_bm_trig,
+                    sizeof(smmc_bm_trig), hipMemcpyHostToDevice);
+  if (err != hipSuccess) {
+    smmc_engine_destroy(e);
+    return fail(SMMC_ERR_HIP, "uploading the Box-Muller tables failed: %s", hipGetErrorString(err));
+  }
   *out = e;
   return SMMC_OK;
 }
@@ -314,6 +334,7 @@ void smmc_engine_destroy(smmc_engine *e) {
   }
   if (e->d_stage_stats) (void)hipFree(e->d_stage_stats);
   if (e->d_table) (void)hipFree(e->d_table);
+  if (e->d_bm_tables) (void)hipFree(e->d_bm_tables);
   if (e->d_partials) (void)hipFree(e->d_partials);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -556,22 +577,20 @@ int smmc_engine_kernel_ms(smmc_engine *e, double *total_ms, uint32_t *launches) 
   return SMMC_OK;
 }
 
-int smmc_engine_selftest(smmc_engine *e, uint32_t bits_lo, uint32_t bits_hi, uint64_t *div_mismatches,
-                         uint64_t *sqrt_mismatches) {
+int smmc_engine_selftest(smmc_engine *e, uint32_t bits_lo, uint32_t bits_hi, uint64_t *div_mismatches) {
   if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
   if (bits_hi < bits_lo) return fail(SMMC_ERR_INVALID, "empty bit-pattern range");
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-  unsigned long long *d = nullptr, h[2] = {0, 0};
+  unsigned long long *d = nullptr, h = 0;
   SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&d), sizeof h));
   hipError_t err = hipMemsetAsync(d, 0, sizeof h, e->stream);
   if (err == hipSuccess && bits_hi > bits_lo) err = smmc::launch_selftest(bits_lo, bits_hi, d, e->max_grid, e->stream);
-  if (err == hipSuccess) err = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, e->stream);
+  if (err == hipSuccess) err = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, e->stream);
   if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
   (void)hipFree(d);
   if (err != hipSuccess) return fail(SMMC_ERR_HIP, "self-test failed: %s", hipGetErrorString(err));
-  if (div_mismatches) *div_mismatches = h[0];
-  if (sqrt_mismatches) *sqrt_mismatches = h[1];
+  if (div_mismatches) *div_mismatches = h;
   return SMMC_OK;
 }
 

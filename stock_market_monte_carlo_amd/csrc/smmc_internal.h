@@ -19,6 +19,7 @@ struct BlockPartial {
 struct KernelArgs {
   int32_t mode;           // SMMC_MODE_*
   const float *table_a;  // device, table_len entries, already 100.0f + r  (MODE_TABLE)
+  const float *bm_tables;  // device, Box-Muller radius + trig tables (MODE_GAUSSIAN), 16-byte aligned
   uint32_t table_len;
   uint32_t key0, key1;   // Philox key = seed lo, hi
   uint64_t first_path;
@@ -44,9 +45,10 @@ hipError_t launch_paths(const KernelArgs &a, bool exact_div, uint32_t grid, size
 hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, smmc_stats *d_stats,
                            uint32_t n_bins, hipStream_t stream);
 hipError_t launch_keepdata(const KernelArgs &a, bool exact_div, int tile, uint32_t grid, hipStream_t stream);
-hipError_t launch_selftest(uint32_t lo, uint32_t hi, unsigned long long *d_counts, uint32_t grid,
+hipError_t launch_selftest(uint32_t lo, uint32_t hi, unsigned long long *d_count, uint32_t grid,
                            hipStream_t stream);
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins);
 size_t keepdata_lds_bytes(uint32_t table_len, int tile);
+size_t bm_tables_bytes();
 
 }  // namespace smmc

@@ -20,13 +20,23 @@ def test_div100_shortcut_is_exact_on_its_whole_domain(oracle):
     assert oracle.div100_mismatches(bits(2.0 ** -126), bits(2.0 ** -124))[0] > 0
 
 
-def test_log_kernel_never_positive_and_accurate(oracle):
-    """Box-Muller takes sqrt(-2 log_kernel(U1)): the kernel must be <= 0 on every U1 in
-    [2^-33, 1] (all 2.8e8 binary32 values) and close to the true logarithm."""
-    positive, worst = oracle.log_kernel_scan(bits(2.0 ** -33), bits(1.0) + 1)
-    assert positive == 0
-    assert worst < 1e-7
-    assert oracle.lib().orc_log_kernel(1.0) == 0.0
+def test_box_muller_radius_table_accuracy(oracle):
+    """r = sqrt(-2 ln((2 ua + 1) / 2^33)) from the piecewise-cubic table: within one
+    binary32 ulp of r (4.8e-7 at the 6.76-sigma end) over a dense sweep of all octaves."""
+    assert oracle.bm_radius_scan(0, 2 ** 32, 499) < 6e-7
+    assert oracle.bm_radius_scan(0, 1 << 20, 1) < 6e-7                   # deepest tail, every value
+    assert oracle.bm_radius_scan((1 << 32) - (1 << 20), 1 << 32, 1) < 6e-7  # U -> 1 end (sqrt singularity)
+    assert oracle.bm_radius_scan((1 << 31) - (1 << 18), (1 << 31) + (1 << 18), 1) < 6e-7  # where the sides meet
+    assert oracle.bm_radius(0) == max(oracle.bm_radius(a) for a in (0, 1, 2, 1000, 2 ** 31))
+    assert abs(oracle.bm_radius(0) - 6.7637) < 1e-3 and 0 < oracle.bm_radius(0xFFFFFFFF) < 2e-5
+
+
+def test_box_muller_tables_identical_in_oracle_and_product():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = open(os.path.join(root, "oracle", "smmc_bm_tables.inc")).read()
+    b = open(os.path.join(root, "stock_market_monte_carlo_amd", "csrc", "smmc_bm_tables.inc")).read()
+    assert a == b and "SMMC_BM_RADIUS_ENTRIES 1024" in a
 
 
 def test_box_muller_moments_and_accuracy(oracle):
@@ -34,16 +44,21 @@ def test_box_muller_moments_and_accuracy(oracle):
     ua = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64)
     ub = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64)
     z = np.array([oracle.box_muller(int(a), int(b)) for a, b in zip(ua, ub)])
-    r = np.sqrt(-2 * np.log(np.float32(ua).astype(np.float64) * 2.0 ** -32 + 2.0 ** -33))
+    r = np.sqrt(-2 * np.log((2 * ua.astype(np.float64) + 1) / 2.0 ** 33))
     th = 2 * np.pi * ub.astype(np.float64) / 2.0 ** 32
     assert np.abs(z[:, 0] - r * np.cos(th)).max() < 2e-6
     assert np.abs(z[:, 1] - r * np.sin(th)).max() < 2e-6
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
-    # extremes of the input words stay finite
-    for a, b in [(0, 0), (0xFFFFFFFF, 0xFFFFFFFF), (0, 0x80000000), (0xFFFFFFFF, 0x40000000), (1, 0x3FFFFFFF)]:
+    # extremes of the input words stay finite and bounded
+    for a, b in [(0, 0), (0xFFFFFFFF, 0xFFFFFFFF), (0, 0x80000000), (0xFFFFFFFF, 0x40000000), (1, 0x3FFFFFFF),
+                 (0x7FFFFFFF, 0x007FFFFF), (0x80000000, 0x00800000), (0x12345678, 0xFF800000)]:
         zc, zs = oracle.box_muller(a, b)
         assert np.isfinite(zc) and np.isfinite(zs) and abs(zc) < 7 and abs(zs) < 7
-    assert oracle.box_muller(0xFFFFFFFF, 123)[0] == 0.0  # U1 rounds to 1 -> radius 0
+        assert abs(np.hypot(zc, zs) - oracle.bm_radius(a)) < 1e-5 * (1 + oracle.bm_radius(a))
+    # angle 0 and the quarter turns come out exact
+    assert oracle.box_muller(0, 0) == (oracle.bm_radius(0), 0.0)
+    zc, zs = oracle.box_muller(0, 0x40000000)
+    assert zc == 0.0 and zs == oracle.bm_radius(0)
 
 
 def test_histogram_bucket_contract(oracle):

@@ -1,9 +1,11 @@
 """Counts the instructions of the innermost period loop of a paths_kernel variant in a
-gfx950 .s file and weights them by the measured issue costs (profiles/r01/ubench_*.txt)."""
+gfx950 .s file and weights them by the measured issue costs relative to a plain VALU op
+(profiles/r01/ubench_instruction_rates.txt, 8 waves/SIMD, warmed up)."""
 import sys
 from collections import Counter
-W = {'v_pk_fma_f32': 1.94, 'v_pk_mul_f32': 1.94, 'v_pk_add_f32': 1.94, 'v_mad_u64_u32': 2.05, 'v_mul_hi_u32': 1.64, 'v_mul_lo_u32': 1.64, 'v_sqrt_f32_e32': 3.25,
-     'v_cvt_f32_u32_e32': 1.7, 'v_cvt_f32_i32_e32': 1.7, 'v_rcp_f32_e32': 3.25, 'v_rsq_f32_e32': 3.25}
+W = {'v_pk_fma_f32': 1.9, 'v_pk_mul_f32': 1.9, 'v_pk_add_f32': 1.9, 'v_mad_u64_u32': 2.29, 'v_mul_hi_u32': 1.78,
+     'v_mul_lo_u32': 1.78, 'v_sqrt_f32_e32': 3.55, 'v_cvt_f32_u32_e32': 1.8, 'v_cvt_f32_i32_e32': 1.8,
+     'v_rcp_f32_e32': 3.55, 'v_rsq_f32_e32': 3.55}
 path, variant = sys.argv[1], sys.argv[2]
 periods = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 lines = open(path).read().splitlines()

@@ -10,8 +10,10 @@
 constexpr int kIters = 4096;
 constexpr int kUnroll = 16;
 
+// shader clock: (memtime ticks, 100 MHz realtime ticks) per workgroup
 template <int OP>
-__global__ __launch_bounds__(256) void probe(unsigned *out, unsigned seed) {
+__global__ __launch_bounds__(256) void probe(unsigned *out, unsigned seed, unsigned long long *clk) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   unsigned a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9E3779B9u, c = a + 12345u, d = b + 777u;
   unsigned long long w0 = a, w1 = b, w2 = c, w3 = d;
   float f0 = a * 1e-9f + 1.0f, f1 = 1.0001f, f2 = 0.5f, f3 = 1.5f;
@@ -56,31 +58,39 @@ __global__ __launch_bounds__(256) void probe(unsigned *out, unsigned seed) {
       }
     }
   }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ (unsigned)w0 ^ (unsigned)w1 ^ (unsigned)w2 ^ (unsigned)w3 ^
                                                __float_as_uint(f0 + f1 + f2 + f3);
 }
 
 template <int OP>
-int run(const char *name, int waves_per_simd, unsigned *d_out, int cus) {
+int run(const char *name, int waves_per_simd, unsigned *d_out, int cus, unsigned long long *d_clk) {
   // blocks of 256 threads = 4 waves = 1 wave per SIMD; `waves_per_simd` blocks per CU
   int grid = cus * waves_per_simd;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(probe<OP>, dim3(grid), dim3(256), 0, 0, d_out, 1u);
+  for (int w = 0; w < 20; ++w) hipLaunchKernelGGL(probe<OP>, dim3(grid), dim3(256), 0, 0, d_out, 1u, d_clk);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL(probe<OP>, dim3(grid), dim3(256), 0, 0, d_out, 2u);
+  hipLaunchKernelGGL(probe<OP>, dim3(grid), dim3(256), 0, 0, d_out, 2u, d_clk);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h(2 * grid);
+  CK(hipMemcpy(h.data(), d_clk, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
+  double ticks = 0, real = 0;
+  for (int i = 0; i < grid; ++i) { ticks += (double)h[2 * i]; real += (double)h[2 * i + 1]; }
+  const double ghz = ticks / real * 0.1;  // memrealtime = 100 MHz
+  const double clk_per_inst = (ticks / grid) / ((double)kIters * kUnroll) / waves_per_simd;  // per SIMD: waves share it
   double insts_per_wave = (double)kIters * kUnroll;  // target instructions per wave
   double waves = (double)grid * 4;
   double total = insts_per_wave * waves;
   double per_simd_per_s = total / (ms * 1e-3) / (cus * 4.0);
-  printf("%-22s waves/SIMD=%d  %8.3f ms  %7.2f Ginst/s/SIMD  => %5.2f clk/inst @2.4GHz\n", name, waves_per_simd, ms,
-         per_simd_per_s * 1e-9, 2.4e9 / per_simd_per_s);
+  printf("%-22s waves/SIMD=%d  %8.3f ms  %7.2f Ginst/s/SIMD  in-kernel clock %.2f GHz  => %5.2f shader-clk/inst/SIMD\n", name,
+         waves_per_simd, ms, per_simd_per_s * 1e-9, ghz, clk_per_inst);
   return 0;
 }
 
@@ -91,18 +101,20 @@ int main() {
   printf("%s CUs=%d clock=%d kHz\n", p.gcnArchName, cus, p.clockRate);
   unsigned *d_out;
   CK(hipMalloc(&d_out, sizeof(unsigned) * cus * 8 * 256));
-  for (int w : {1, 2, 4, 8}) {
-    run<0>("v_xor_b32", w, d_out, cus);
-    run<1>("v_mul_lo_u32", w, d_out, cus);
-    run<2>("v_mul_hi_u32", w, d_out, cus);
-    run<3>("v_mad_u64_u32(+.5xor)", w, d_out, cus);
-    run<4>("v_fma_f32", w, d_out, cus);
-    run<5>("v_mul_u32_u24", w, d_out, cus);
-    run<6>("v_mul_hi_u32_u24", w, d_out, cus);
-    run<7>("v_sqrt_f32", w, d_out, cus);
-    run<8>("v_cvt_f32_u32", w, d_out, cus);
-    run<9>("v_pk_fma_f32", w, d_out, cus);
-    run<10>("div100 chain(4 inst)", w, d_out, cus);
+  unsigned long long *d_clk;
+  CK(hipMalloc(&d_clk, sizeof(unsigned long long) * 2 * cus * 8));
+  for (int w : {2, 8}) {
+    run<0>("v_xor_b32", w, d_out, cus, d_clk);
+    run<1>("v_mul_lo_u32", w, d_out, cus, d_clk);
+    run<2>("v_mul_hi_u32", w, d_out, cus, d_clk);
+    run<3>("v_mad_u64_u32(+.5xor)", w, d_out, cus, d_clk);
+    run<4>("v_fma_f32", w, d_out, cus, d_clk);
+    run<5>("v_mul_u32_u24", w, d_out, cus, d_clk);
+    run<6>("v_mul_hi_u32_u24", w, d_out, cus, d_clk);
+    run<7>("v_sqrt_f32", w, d_out, cus, d_clk);
+    run<8>("v_cvt_f32_u32", w, d_out, cus, d_clk);
+    run<9>("v_pk_fma_f32", w, d_out, cus, d_clk);
+    run<10>("div100 chain(4 inst)", w, d_out, cus, d_clk);
   }
   return 0;
 }
