@@ -13,8 +13,8 @@
  * engines may be used concurrently.  No call exits the process: every failure
  * is a negative return code plus smmc_last_error() (thread-local text).
  *
- * Random stream ("counter stream v1"): Philox4x32-10, key =
- * the 64-bit seed, counter = (global path id, period/4, mode).  A path's value
+ * Random stream ("counter stream v2"): Philox4x32-10, key =
+ * the 64-bit seed, counter = (global path id, block of periods, mode).  A path's value
  * depends only on (seed, global path id, parameters), never on the launch
  * geometry, the shard it falls in or the number of GPUs.
  */

@@ -3,7 +3,7 @@
 # Kernel-trace/stats and each PMC group are separate rocprofv3 runs.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/prof_r01
+OUT=$R/gpurun_out/${PROF_TAG:-prof_r01}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
