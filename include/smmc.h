@@ -171,6 +171,36 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
 int smmc_engine_simulate_keepdata_to_host(smmc_engine *e, const smmc_sim *sim, float *host_traj,
                                           float *host_final);
 
+/* ---- statistics of values already in HBM ---------------------------- */
+
+#define SMMC_MAX_RANKS 8
+
+/* One pass over n device floats -> packed statistics record (d_stats, device,
+ * smmc_stats_bytes(n_bins) bytes): sum, sum of squares, count below a threshold, min,
+ * max, bucket histogram.  Replaces the host passes update_mean_std and
+ * update_count_below_min of the reference's callers (examples/visualize_returns_cpu_v2.cpp:
+ * 113-138, examples/benchmark_mc_gpu.cpp:7-41) on data that never leaves the GPU.
+ * Asynchronous on the engine stream. */
+int smmc_engine_values_stats(smmc_engine *e, const float *d_values, uint64_t n, float below_threshold,
+                             uint32_t n_bins, float hist_lo, float hist_hi, void *d_stats);
+
+/* Exact order statistics: host_out[q] = the ranks[q]-th smallest (0-based) of n device
+ * floats, n_ranks <= SMMC_MAX_RANKS, every rank < n.  Three histogram passes of radix
+ * selection; the input is not modified or copied.  Synchronous. */
+int smmc_engine_order_statistics(smmc_engine *e, const float *d_values, uint64_t n, const uint64_t *ranks,
+                                 uint32_t n_ranks, float *host_out);
+
+/* {min, Q1, Q2, Q3, max} with Q1 = n/4, Q2 = n/2, Q3 = Q1 + Q2 as ranks in sorted order:
+ * update_quartiles, examples/visualize_returns_cpu_v2.cpp:83-111.  n >= 1.  Synchronous. */
+int smmc_engine_quartiles(smmc_engine *e, const float *d_values, uint64_t n, float host_out[5]);
+
+/* Mean of n HOST floats: chunked host-to-device copy + values_stats, double
+ * accumulation; *mean = (float)sum / n as the CPU check of
+ * examples/benchmark_reduce_mean.cpp:31-32.  reduce_mean_gpu, src/simulations.cu:269-341
+ * (which sums in float by an in-place strided tree and overflows int indices beyond
+ * 2^31 elements).  sum may be NULL.  Synchronous. */
+int smmc_engine_reduce_mean_host(smmc_engine *e, const float *host_values, uint64_t n, float *mean, double *sum);
+
 /* Device-time instrumentation: when enabled, every simulate call brackets its
  * main kernel with HIP events on the engine stream.  smmc_engine_kernel_ms
  * synchronises, returns the number of timed launches and their summed duration

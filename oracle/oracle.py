@@ -84,6 +84,10 @@ def lib():
         L.orc_draws_per_block.restype = C.c_uint32
         L.orc_draws_per_block.argtypes = [C.c_int32, C.c_uint32]
         L.orc_chunk_mean_var.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_values_stats.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_uint32, C.c_float, C.c_float,
+                                       C.POINTER(Stats), C.c_void_p]
+        L.orc_order_statistics.restype = C.c_int
+        L.orc_order_statistics.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -221,3 +225,30 @@ def bm_radius(ua):
 
 def bm_radius_scan(lo, hi, stride):
     return float(lib().orc_bm_radius_scan(C.c_uint64(lo), C.c_uint64(hi), C.c_uint64(stride)))
+
+
+def values_stats(values, below_threshold=1000.0, n_bins=0, lo=0.0, hi=1.0):
+    v = _f32(values)
+    st = Stats()
+    hist = np.zeros(max(n_bins, 1), dtype=np.uint64)
+    lib().orc_values_stats(v.ctypes.data_as(C.c_void_p), v.size, below_threshold, n_bins, lo, hi, C.byref(st),
+                           hist.ctypes.data_as(C.c_void_p) if n_bins else None)
+    return st, hist[:n_bins]
+
+
+def order_statistics(values, ranks):
+    v = _f32(values)
+    r = np.ascontiguousarray(ranks, dtype=np.uint64)
+    out = np.empty(r.size, dtype=np.float32)
+    rc = lib().orc_order_statistics(v.ctypes.data_as(C.c_void_p), v.size, r.ctypes.data_as(C.c_void_p), r.size,
+                                    out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("orc_order_statistics failed")
+    return out
+
+
+def quartiles(values):
+    """examples/visualize_returns_cpu_v2.cpp:96-111: ranks 0, n/4, n/2, n/4 + n/2, n - 1."""
+    n = len(values)
+    q1, q2 = n // 4, n // 2
+    return order_statistics(values, [0, q1, q2, min(q1 + q2, n - 1), n - 1])

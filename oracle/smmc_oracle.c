@@ -478,3 +478,51 @@ ORC_API double orc_bm_radius_scan(uint64_t lo, uint64_t hi, uint64_t stride) {
   }
   return worst;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Statistics of an array of values (the callers' passes over final_values)   */
+/* ------------------------------------------------------------------------- */
+
+/* Same record as orc_counter_mc computes, for an arbitrary array: sequential double sums
+ * (examples/visualize_returns_cpu_v2.cpp:113-138, examples/benchmark_mc_gpu.cpp:7-41). */
+ORC_API void orc_values_stats(const float *v, uint64_t n, float below_threshold, uint32_t n_bins, float lo,
+                              float hi, orc_stats *out, uint64_t *hist) {
+  orc_stats s;
+  memset(&s, 0, sizeof s);
+  s.min = INFINITY;
+  s.max = -INFINITY;
+  if (hist) memset(hist, 0, sizeof(uint64_t) * n_bins);
+  for (uint64_t i = 0; i < n; i++) {
+    float x = v[i];
+    s.count++;
+    if (x < below_threshold) s.below++;
+    s.sum += (double)x;
+    s.sumsq += (double)x * (double)x;
+    if (x < s.min) s.min = x;
+    if (x > s.max) s.max = x;
+    if (n_bins) {
+      int32_t b = orc_hist_bucket(x, lo, hi, n_bins);
+      if (b < 0) s.underflow++;
+      else if (b >= (int32_t)n_bins) s.overflow++;
+      else if (hist) hist[b]++;
+    }
+  }
+  *out = s;
+}
+
+static int cmp_float(const void *a, const void *b) {
+  float x = *(const float *)a, y = *(const float *)b;
+  return (x > y) - (x < y);
+}
+
+/* k-th smallest (0-based) by fully sorting a copy -- what examples/visualize_returns_gpu.cpp:
+ * 108-109 does with std::sort (and :83-111 of the cpu_v2 twin with std::nth_element). */
+ORC_API int orc_order_statistics(const float *v, uint64_t n, const uint64_t *ranks, uint32_t n_ranks, float *out) {
+  float *copy = (float *)malloc(sizeof(float) * (size_t)(n ? n : 1));
+  if (!copy) return -2;
+  memcpy(copy, v, sizeof(float) * (size_t)n);
+  qsort(copy, (size_t)n, sizeof(float), cmp_float);
+  for (uint32_t q = 0; q < n_ranks; q++) out[q] = copy[ranks[q]];
+  free(copy);
+  return 0;
+}

@@ -16,6 +16,7 @@ FLAG_EXACT_DIV = 1
 CHUNK = 256
 MAX_TABLE = 16384
 MAX_BINS = 4096
+MAX_RANKS = 8
 
 
 class Sim(C.Structure):
@@ -71,6 +72,13 @@ SYMBOLS = [
     ("smmc_engine_simulate_to_host", C.c_int,
      [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     ("smmc_engine_simulate_keepdata_to_host", C.c_int, [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p]),
+    ("smmc_engine_values_stats", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
+    ("smmc_engine_order_statistics", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("smmc_engine_quartiles", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("smmc_engine_reduce_mean_host", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     ("smmc_engine_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("smmc_engine_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     ("smmc_engine_selftest", C.c_int,

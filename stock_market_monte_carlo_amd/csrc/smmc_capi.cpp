@@ -91,6 +91,12 @@ struct smmc_engine {
   hipEvent_t ev_compute[2] = {nullptr, nullptr};
   hipEvent_t ev_copy[2] = {nullptr, nullptr};
 
+  // order statistics workspace
+  smmc::SelectState *d_select = nullptr;
+  unsigned long long *d_radix_hist = nullptr;  // kMaxRanks x 2048
+  float *d_select_out = nullptr;               // kMaxRanks
+  void *d_scratch_stats = nullptr;             // one packed record with SMMC_MAX_BINS buckets
+
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;  // pairs: start, stop
   size_t ev_used = 0;
@@ -335,6 +341,10 @@ void smmc_engine_destroy(smmc_engine *e) {
   if (e->d_stage_stats) (void)hipFree(e->d_stage_stats);
   if (e->d_table) (void)hipFree(e->d_table);
   if (e->d_bm_tables) (void)hipFree(e->d_bm_tables);
+  if (e->d_select) (void)hipFree(e->d_select);
+  if (e->d_radix_hist) (void)hipFree(e->d_radix_hist);
+  if (e->d_select_out) (void)hipFree(e->d_select_out);
+  if (e->d_scratch_stats) (void)hipFree(e->d_scratch_stats);
   if (e->d_partials) (void)hipFree(e->d_partials);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -552,6 +562,141 @@ int smmc_engine_simulate_keepdata_to_host(smmc_engine *e, const smmc_sim *sim, f
   if (d_fin) (void)hipFree(d_fin);
   if (rc) return rc;
   if (err != hipSuccess) return fail(SMMC_ERR_HIP, "keepdata_to_host failed: %s", hipGetErrorString(err));
+  return SMMC_OK;
+}
+
+int smmc_engine_values_stats(smmc_engine *e, const float *d_values, uint64_t n, float below_threshold,
+                             uint32_t n_bins, float hist_lo, float hist_hi, void *d_stats) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  if (!d_stats) return fail(SMMC_ERR_INVALID, "d_stats is NULL");
+  if (n && !d_values) return fail(SMMC_ERR_INVALID, "d_values is NULL");
+  if (n_bins > SMMC_MAX_BINS) return fail(SMMC_ERR_INVALID, "n_bins %u exceeds SMMC_MAX_BINS %d", n_bins, SMMC_MAX_BINS);
+  if (n_bins && (!(hist_lo < hist_hi) || !std::isfinite(hist_lo) || !std::isfinite(hist_hi)))
+    return fail(SMMC_ERR_INVALID, "histogram range must be finite with lo < hi");
+  if (reinterpret_cast<uintptr_t>(d_values) & 3u) return fail(SMMC_ERR_INVALID, "d_values must be 4-byte aligned");
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  SMMC_HIP(hipMemsetAsync(d_stats, 0, smmc_stats_bytes(n_bins), e->stream));
+  smmc::ValuesArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.values = d_values;
+  a.n = n;
+  a.below_threshold = below_threshold;
+  a.n_bins = n_bins;
+  a.hist_copies = smmc::values_hist_copies(n_bins);
+  a.hist_lo = hist_lo;
+  a.hist_hi = hist_hi;
+  a.hist_inv = n_bins ? static_cast<double>(n_bins) / (static_cast<double>(hist_hi) - static_cast<double>(hist_lo)) : 0.0;
+  a.partials = e->d_partials;
+  a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
+  // 16 bytes per lane per iteration; enough workgroups to keep every CU's memory pipe full
+  const uint64_t want = (n / 4 + smmc::kBlock - 1) / smmc::kBlock;
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min(e->compute_units * 16u, e->max_grid)));
+  if (n) {
+    int rc = timing_begin(e);
+    if (rc) return rc;
+    SMMC_HIP(smmc::launch_values_stats(a, grid, e->stream));
+    rc = timing_end(e);
+    if (rc) return rc;
+  }
+  SMMC_HIP(smmc::launch_finalize(e->d_partials, n ? grid : 0u, static_cast<smmc_stats *>(d_stats), n_bins, e->stream));
+  return SMMC_OK;
+}
+
+int smmc_engine_order_statistics(smmc_engine *e, const float *d_values, uint64_t n, const uint64_t *ranks,
+                                 uint32_t n_ranks, float *host_out) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  if (!d_values || !ranks || !host_out) return fail(SMMC_ERR_INVALID, "NULL argument");
+  if (n_ranks == 0 || n_ranks > SMMC_MAX_RANKS) return fail(SMMC_ERR_INVALID, "n_ranks must be in [1, %d]", SMMC_MAX_RANKS);
+  if (reinterpret_cast<uintptr_t>(d_values) & 3u) return fail(SMMC_ERR_INVALID, "d_values must be 4-byte aligned");
+  for (uint32_t q = 0; q < n_ranks; ++q)
+    if (ranks[q] >= n) return fail(SMMC_ERR_INVALID, "rank %llu is not below n = %llu", (unsigned long long)ranks[q], (unsigned long long)n);
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  const size_t hist_bytes = sizeof(unsigned long long) * smmc::kMaxRanks * 2048;
+  if (!e->d_select) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_select), sizeof(smmc::SelectState)));
+  if (!e->d_radix_hist) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_radix_hist), hist_bytes));
+  if (!e->d_select_out) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_select_out), sizeof(float) * smmc::kMaxRanks));
+  smmc::SelectState st;
+  std::memset(&st, 0, sizeof st);
+  for (uint32_t q = 0; q < n_ranks; ++q) st.rank[q] = ranks[q];
+  SMMC_HIP(hipMemcpyAsync(e->d_select, &st, sizeof st, hipMemcpyHostToDevice, e->stream));
+  SMMC_HIP(hipStreamSynchronize(e->stream));  // `st` is a local
+  // 1024-thread workgroups, two per CU (the LDS histograms allow no more), grid-stride
+  const uint64_t want = (n / 8 + 1023) / 1024;
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(want, 1), e->compute_units * 2u));
+  for (int pass = 0; pass < 3; ++pass) {
+    SMMC_HIP(hipMemsetAsync(e->d_radix_hist, 0, hist_bytes, e->stream));
+    int rc = timing_begin(e);
+    if (rc) return rc;
+    SMMC_HIP(smmc::launch_radix_hist(d_values, n, pass, n_ranks, e->d_select, e->d_radix_hist, grid, e->stream));
+    rc = timing_end(e);
+    if (rc) return rc;
+    SMMC_HIP(smmc::launch_radix_pick(pass, n_ranks, e->d_select, e->d_radix_hist, e->d_select_out, e->stream));
+  }
+  SMMC_HIP(hipMemcpyAsync(host_out, e->d_select_out, sizeof(float) * n_ranks, hipMemcpyDeviceToHost, e->stream));
+  SMMC_HIP(hipStreamSynchronize(e->stream));
+  return SMMC_OK;
+}
+
+int smmc_engine_quartiles(smmc_engine *e, const float *d_values, uint64_t n, float host_out[5]) {
+  if (n == 0) return fail(SMMC_ERR_INVALID, "quartiles of an empty array");
+  // examples/visualize_returns_cpu_v2.cpp:96-98
+  const uint64_t q1 = n / 4, q2 = n / 2, q3 = q1 + q2;
+  const uint64_t ranks[5] = {0, q1, q2, q3 < n ? q3 : n - 1, n - 1};
+  return smmc_engine_order_statistics(e, d_values, n, ranks, 5, host_out);
+}
+
+int smmc_engine_reduce_mean_host(smmc_engine *e, const float *host_values, uint64_t n, float *mean, double *sum) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  if (!mean) return fail(SMMC_ERR_INVALID, "mean is NULL");
+  if (n == 0) return fail(SMMC_ERR_INVALID, "mean of an empty array");
+  if (!host_values) return fail(SMMC_ERR_INVALID, "host_values is NULL");
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  const uint64_t chunk = std::min<uint64_t>(n, kHostChunkPaths);
+  if (e->stage_paths < chunk) {
+    for (int i = 0; i < 2; ++i) {
+      if (e->d_stage[i]) SMMC_HIP(hipFree(e->d_stage[i]));
+      e->d_stage[i] = nullptr;
+    }
+    e->stage_paths = 0;
+    for (int i = 0; i < 2; ++i) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_stage[i]), sizeof(float) * chunk));
+    e->stage_paths = chunk;
+  }
+  if (!e->copy_stream) SMMC_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    if (!e->ev_compute[i]) SMMC_HIP(hipEventCreateWithFlags(&e->ev_compute[i], hipEventDisableTiming));
+    if (!e->ev_copy[i]) SMMC_HIP(hipEventCreateWithFlags(&e->ev_copy[i], hipEventDisableTiming));
+  }
+  const uint64_t n_chunks = (n + chunk - 1) / chunk;
+  const size_t rec = smmc_stats_bytes(0);
+  if (e->stage_stats_bytes < rec * n_chunks) {
+    if (e->d_stage_stats) SMMC_HIP(hipFree(e->d_stage_stats));
+    e->d_stage_stats = nullptr;
+    e->stage_stats_bytes = 0;
+    SMMC_HIP(hipMalloc(&e->d_stage_stats, rec * n_chunks));
+    e->stage_stats_bytes = rec * n_chunks;
+  }
+  // H2D of chunk c (copy stream) overlaps the reduction of chunk c - 1 (engine stream)
+  for (uint64_t c = 0; c < n_chunks; ++c) {
+    const int b = static_cast<int>(c & 1);
+    const uint64_t count = std::min<uint64_t>(chunk, n - c * chunk);
+    if (c >= 2) SMMC_HIP(hipStreamWaitEvent(e->copy_stream, e->ev_compute[b], 0));
+    SMMC_HIP(hipMemcpyAsync(e->d_stage[b], host_values + c * chunk, sizeof(float) * count, hipMemcpyHostToDevice, e->copy_stream));
+    SMMC_HIP(hipEventRecord(e->ev_copy[b], e->copy_stream));
+    SMMC_HIP(hipStreamWaitEvent(e->stream, e->ev_copy[b], 0));
+    int rc = smmc_engine_values_stats(e, e->d_stage[b], count, 0.f, 0, 0.f, 1.f, static_cast<char *>(e->d_stage_stats) + rec * c);
+    if (rc) return rc;
+    SMMC_HIP(hipEventRecord(e->ev_compute[b], e->stream));
+  }
+  std::vector<smmc_stats> recs(n_chunks);
+  SMMC_HIP(hipMemcpyAsync(recs.data(), e->d_stage_stats, rec * n_chunks, hipMemcpyDeviceToHost, e->stream));
+  SMMC_HIP(hipStreamSynchronize(e->stream));
+  double total = 0.0;
+  for (uint64_t c = 0; c < n_chunks; ++c) total += recs[c].sum;  // chunk order
+  if (sum) *sum = total;
+  *mean = static_cast<float>(total) / static_cast<float>(n);
   return SMMC_OK;
 }
 

@@ -39,6 +39,39 @@ struct KernelArgs {
   float *d_traj;         // keepdata only: n_paths x (n_periods + 1), path-major
 };
 
+// values_stats_kernel arguments (smmc_stats_kernels.hip)
+struct ValuesArgs {
+  const float *values;
+  uint64_t n;
+  float below_threshold;
+  uint32_t n_bins;
+  uint32_t hist_copies;  // lane-interleaved LDS histogram copies (values_hist_copies)
+  float hist_lo, hist_hi;
+  double hist_inv;
+  BlockPartial *partials;
+  unsigned long long *d_hist;
+};
+uint32_t values_hist_copies(uint32_t n_bins);
+
+// radix selection state: per requested rank, the key bits fixed so far and the rank
+// relative to the values that share those bits
+constexpr uint32_t kMaxRanks = 8;
+struct SelectState {
+  uint32_t prefix[kMaxRanks];
+  unsigned long long rank[kMaxRanks];
+  // ranks that share a prefix share one histogram ("group"): a value then costs at most
+  // one LDS atomic per pass however many ranks were asked for
+  uint32_t n_groups;
+  uint32_t group_prefix[kMaxRanks];
+  uint32_t group_of[kMaxRanks];
+};
+
+hipError_t launch_values_stats(const ValuesArgs &a, uint32_t grid, hipStream_t stream);
+hipError_t launch_radix_hist(const float *values, uint64_t n, int pass, uint32_t n_ranks, const SelectState *st,
+                             unsigned long long *g_hist, uint32_t grid, hipStream_t stream);
+hipError_t launch_radix_pick(int pass, uint32_t n_ranks, SelectState *st, const unsigned long long *g_hist,
+                             float *d_out, hipStream_t stream);
+
 // Launch wrappers (defined in smmc_kernels.hip).  All asynchronous on `stream`.
 hipError_t launch_paths(const KernelArgs &a, bool exact_div, uint32_t grid, size_t lds_bytes,
                         hipStream_t stream);

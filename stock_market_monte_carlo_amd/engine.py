@@ -183,6 +183,46 @@ class Engine:
         self.sync()
         return stats_from_bytes(stats_raw.cpu().numpy().tobytes())
 
+    # -- statistics of values already in HBM ---------------------
+    def _check_values(self, values):
+        torch = self._torch
+        if not (values.is_cuda and values.dtype == torch.float32 and values.is_contiguous() and values.dim() == 1):
+            raise ValueError("values must be a contiguous 1-D float32 tensor on the engine's device")
+
+    def values_stats(self, values, below_threshold=1000.0, n_bins=0, hist_lo=0.0, hist_hi=1.0):
+        """One HBM pass over a device tensor -> packed statistics record (device uint8 tensor)."""
+        self._check_values(values)
+        rec = self._torch.empty(int(self._L.smmc_stats_bytes(n_bins)), dtype=self._torch.uint8, device=self.tdevice)
+        _lib.check(self._L.smmc_engine_values_stats(self._h, C.c_void_p(values.data_ptr()), values.numel(),
+                                                    below_threshold, n_bins, hist_lo, hist_hi,
+                                                    C.c_void_p(rec.data_ptr())))
+        return rec
+
+    def order_statistics(self, values, ranks):
+        """Exact k-th smallest values (0-based ranks) of a device tensor, unsorted input."""
+        self._check_values(values)
+        r = np.ascontiguousarray(ranks, dtype=np.uint64)
+        out = np.empty(r.size, dtype=np.float32)
+        _lib.check(self._L.smmc_engine_order_statistics(self._h, C.c_void_p(values.data_ptr()), values.numel(),
+                                                        r.ctypes.data_as(C.c_void_p), r.size,
+                                                        out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def quartiles(self, values):
+        """{min, Q1, Q2, Q3, max}: update_quartiles, examples/visualize_returns_cpu_v2.cpp:83-111."""
+        self._check_values(values)
+        out = np.empty(5, dtype=np.float32)
+        _lib.check(self._L.smmc_engine_quartiles(self._h, C.c_void_p(values.data_ptr()), values.numel(),
+                                                 out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def reduce_mean_host(self, host_values):
+        v = np.ascontiguousarray(host_values, dtype=np.float32)
+        mean, total = C.c_float(), C.c_double()
+        _lib.check(self._L.smmc_engine_reduce_mean_host(self._h, v.ctypes.data_as(C.c_void_p), v.size,
+                                                        C.byref(mean), C.byref(total)))
+        return mean.value, total.value
+
     def simulate_keepdata(self, sim, want_final=True):
         torch = self._torch
         n, p = int(sim.n_paths), int(sim.n_periods)
@@ -330,3 +370,35 @@ def mc_simulations_keepdata(max_n_simulations, n_periods, initial_capital, histo
     e.set_table(historical_returns)
     sim = Engine.make_sim(int(max_n_simulations), n_periods, MODE_TABLE, _seed(seed), initial_capital=initial_capital)
     return e.simulate_keepdata_to_host(sim)
+
+
+def reduce_mean_gpu(vec, n=None):
+    """simulations.h:71, src/simulations.cu:269-341: mean of the first n entries of a host array."""
+    v = np.ascontiguousarray(vec, dtype=np.float32)
+    n = v.size if n is None else int(n)
+    return _engine(0).reduce_mean_host(v[:n])[0]
+
+
+def _to_device(values, n_el):
+    import torch
+    v = np.ascontiguousarray(values, dtype=np.float32)[: int(n_el)]
+    return torch.from_numpy(v).to(_engine(0).tdevice)
+
+
+def update_quartiles(vec, n_el):
+    """examples/visualize_returns_cpu_v2.cpp:83-111: [min, Q1, Q2, Q3, max] of vec[:n_el]."""
+    return _engine(0).quartiles(_to_device(vec, n_el))
+
+
+def update_mean_std(v, n_el):
+    """examples/visualize_returns_cpu_v2.cpp:113-123: (mean, population std) as floats."""
+    e = _engine(0)
+    st = e.read_stats(e.values_stats(_to_device(v, n_el)))
+    mean = np.float32(st.sum / n_el)
+    return float(mean), float(np.float32(np.sqrt(st.sumsq / n_el - float(mean) * float(mean))))
+
+
+def update_count_below_min(min_final_amount, final_values, n_simulations):
+    """examples/visualize_returns_cpu_v2.cpp:125-138: count of final_values[:n] < min_final_amount."""
+    e = _engine(0)
+    return e.read_stats(e.values_stats(_to_device(final_values, n_simulations), below_threshold=min_final_amount)).below
