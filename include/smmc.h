@@ -201,6 +201,13 @@ int smmc_engine_quartiles(smmc_engine *e, const float *d_values, uint64_t n, flo
  * 2^31 elements).  sum may be NULL.  Synchronous. */
 int smmc_engine_reduce_mean_host(smmc_engine *e, const float *host_values, uint64_t n, float *mean, double *sum);
 
+/* The same two operations on n HOST floats (copied to the device once, synchronous):
+ * what update_quartiles / update_mean_std / update_count_below_min of the reference's
+ * examples do on their std::vector.  stats and hist may be NULL, quartiles may be NULL. */
+int smmc_engine_host_values_summary(smmc_engine *e, const float *host_values, uint64_t n, float below_threshold,
+                                    uint32_t n_bins, float hist_lo, float hist_hi, smmc_stats *stats,
+                                    uint64_t *hist, float quartiles[5]);
+
 /* Device-time instrumentation: when enabled, every simulate call brackets its
  * main kernel with HIP events on the engine stream.  smmc_engine_kernel_ms
  * synchronises, returns the number of timed launches and their summed duration

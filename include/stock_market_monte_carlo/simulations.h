@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include "helpers.h"  // the reference header includes it too (simulations.h:7)
+
 // ---- compounding core (src/simulations.cpp:14-39) ------------------------------------
 float update_fund(float fund_value, float period_return);                             // :14-16
 void __many_updates(float *returns, float *totals, unsigned int n_periods);           // :18-22
@@ -54,6 +56,11 @@ void mc_simulations_gpu_reduceBlock(std::atomic<long> &n_simulations, long max_n
                                     float initial_capital, std::vector<float> &returns,
                                     std::vector<float> &means, std::vector<float> &variances, int n_gpus);
 
+// ---- mean of a host array on the GPU (src/simulations.cu:269-341) ----------------------
+// Mean of the first n entries of vec; double accumulation on the device (the reference
+// sums in float through an in-place strided tree and indexes with int).
+float reduce_mean_gpu(std::vector<float> &vec, long n);
+
 // ---- additions (not in the reference) ---------------------------------------------------
 namespace smmc {
 
@@ -82,6 +89,14 @@ struct Summary {
 Summary mc_summary(long max_n_simulations, int n_periods, float initial_capital, bool gaussian,
                    std::vector<float> &returns, float return_mean, float return_std, float below_threshold,
                    unsigned n_bins, float hist_lo, float hist_hi, int n_gpus);
+
+// The statistics helpers the reference keeps in its example programs
+// (examples/visualize_returns_cpu_v2.cpp:83-138), executed on the GPU: the prefix
+// vec[0 .. n_el) is copied to the device once per call.  quartiles becomes
+// {min, Q1, Q2, Q3, max} by exact selection (no sort, the input is not modified).
+void update_quartiles(std::vector<float> &quartiles, std::vector<float> &vec, long n_el);
+void update_mean_std(float &mean, float &std, std::vector<float> &v, long n_el);
+long update_count_below_min(float &min_final_amount, const std::vector<float> &final_values, long n_simulations);
 
 // The 1127-entry synthetic returns table bundled with the library (percent units),
 // used by the CLIs when data/SP500_monthly_returns.csv is absent.

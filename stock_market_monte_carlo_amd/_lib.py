@@ -79,6 +79,9 @@ SYMBOLS = [
     ("smmc_engine_quartiles", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     ("smmc_engine_reduce_mean_host", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    ("smmc_engine_host_values_summary", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_uint32, C.c_float, C.c_float, C.POINTER(Stats),
+      C.c_void_p, C.c_void_p]),
     ("smmc_engine_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("smmc_engine_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     ("smmc_engine_selftest", C.c_int,

@@ -700,6 +700,39 @@ int smmc_engine_reduce_mean_host(smmc_engine *e, const float *host_values, uint6
   return SMMC_OK;
 }
 
+int smmc_engine_host_values_summary(smmc_engine *e, const float *host_values, uint64_t n, float below_threshold,
+                                    uint32_t n_bins, float hist_lo, float hist_hi, smmc_stats *stats,
+                                    uint64_t *hist, float quartiles[5]) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  if (n == 0 || !host_values) return fail(SMMC_ERR_INVALID, "empty input");
+  if (n_bins > SMMC_MAX_BINS) return fail(SMMC_ERR_INVALID, "n_bins %u exceeds SMMC_MAX_BINS %d", n_bins, SMMC_MAX_BINS);
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  float *d = nullptr;
+  SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&d), sizeof(float) * n));
+  int rc = SMMC_OK;
+  hipError_t err = hipMemcpyAsync(d, host_values, sizeof(float) * n, hipMemcpyHostToDevice, e->stream);
+  if (err == hipSuccess && !e->d_scratch_stats) err = hipMalloc(&e->d_scratch_stats, smmc_stats_bytes(SMMC_MAX_BINS));
+  if (err == hipSuccess && (stats || hist)) {
+    rc = smmc_engine_values_stats(e, d, n, below_threshold, n_bins, hist_lo, hist_hi, e->d_scratch_stats);
+    if (rc == SMMC_OK) {
+      std::vector<char> rec(smmc_stats_bytes(n_bins));
+      err = hipMemcpyAsync(rec.data(), e->d_scratch_stats, rec.size(), hipMemcpyDeviceToHost, e->stream);
+      if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+      if (err == hipSuccess) {
+        if (stats) std::memcpy(stats, rec.data(), sizeof(smmc_stats));
+        if (hist && n_bins) std::memcpy(hist, rec.data() + sizeof(smmc_stats), sizeof(uint64_t) * n_bins);
+      }
+    }
+  }
+  if (err == hipSuccess && rc == SMMC_OK && quartiles) rc = smmc_engine_quartiles(e, d, n, quartiles);
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  (void)hipFree(d);
+  if (rc) return rc;
+  if (err != hipSuccess) return fail(SMMC_ERR_HIP, "host_values_summary failed: %s", hipGetErrorString(err));
+  return SMMC_OK;
+}
+
 int smmc_engine_timing(smmc_engine *e, int enable) {
   if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
   e->timing = enable != 0;

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <filesystem>
 #include <fstream>
 #include <map>
 #include <memory>
@@ -302,9 +303,69 @@ void mc_simulations_gpu_reduceBlock(std::atomic<long> &n_simulations, long max_n
   n_simulations = max_n_simulations;  // src/simulations.cu:695
 }
 
+float reduce_mean_gpu(std::vector<float> &vec, long n) {
+  if (n <= 0 || static_cast<size_t>(n) > vec.size()) throw std::invalid_argument("smmc: reduce_mean_gpu needs 0 < n <= vec.size()");
+  Session ses(0, nullptr);
+  float mean = 0.f;
+  check(smmc_engine_reduce_mean_host(ses.engine, vec.data(), static_cast<std::uint64_t>(n), &mean, nullptr));
+  return mean;
+}
+
+// ---- CSV writers (src/helpers.cpp) ------------------------------------------------------------------
+
+void print_vector(std::vector<float> &v) {
+  std::printf("v = [ ");
+  for (float x : v) std::printf("%6.3f ", x);
+  std::printf(" ]\n");
+}
+
+void write_vector_file(std::string fname, std::vector<float> &v) {
+  std::ofstream out(fname);
+  for (float x : v) out << x << ",";
+}
+
+void write_data_file(std::string fname, std::vector<float> &returns, std::vector<float> &values) {
+  std::printf("Writing data to csv file outputs/%s\n", fname.c_str());
+  const std::string dir = "./outputs/";
+  std::filesystem::create_directory(dir);
+  std::ofstream out(dir + "/" + fname);
+  out << "Returns,,";  // the double comma is the reference's (src/helpers.cpp:31): values[0] has no return
+  for (float x : returns) out << x << ",";
+  out << "\nValues,";
+  for (float x : values) out << x << ",";
+}
+
 // ---- additions -----------------------------------------------------------------------------------
 
 namespace smmc {
+
+namespace {
+void summary_of(const std::vector<float> &v, long n_el, float below, smmc_stats *st, float *quart) {
+  if (n_el <= 0 || static_cast<size_t>(n_el) > v.size()) throw std::invalid_argument("smmc: need 0 < n_el <= vec.size()");
+  Session ses(0, nullptr);
+  check(smmc_engine_host_values_summary(ses.engine, v.data(), static_cast<std::uint64_t>(n_el), below, 0, 0.f, 1.f, st,
+                                        nullptr, quart));
+}
+}  // namespace
+
+void update_quartiles(std::vector<float> &quartiles, std::vector<float> &vec, long n_el) {
+  float q[5];
+  summary_of(vec, n_el, 0.f, nullptr, q);
+  quartiles.assign(q, q + 5);  // {min, Q1, Q2, Q3, max}, examples/visualize_returns_cpu_v2.cpp:110
+}
+
+void update_mean_std(float &mean, float &std, std::vector<float> &v, long n_el) {
+  smmc_stats st;
+  summary_of(v, n_el, 0.f, &st, nullptr);
+  mean = static_cast<float>(st.sum / static_cast<double>(n_el));  // examples/visualize_returns_cpu_v2.cpp:117-122
+  std = static_cast<float>(std::sqrt(st.sumsq / static_cast<double>(n_el) - static_cast<double>(mean) * mean));
+}
+
+long update_count_below_min(float &min_final_amount, const std::vector<float> &final_values, long n_simulations) {
+  smmc_stats st;
+  summary_of(final_values, n_simulations, min_final_amount, &st, nullptr);
+  return static_cast<long>(st.below);
+}
 
 void fix_seed(bool fixed, std::uint64_t seed) {
   std::lock_guard<std::mutex> lock(g_seed_mutex);

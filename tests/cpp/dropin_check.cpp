@@ -68,7 +68,23 @@ int main(int argc, char **argv) {
   std::uint64_t hist_total = 0;
   for (auto c : s.hist) hist_total += c;
 
-  std::printf("{\"n\": %ld, \"gpu_hash\": %" PRIu64 ", \"cpu_hash\": %" PRIu64 ", \"counter_gpu\": %ld, \"seen_mid\": %ld, "
+  // statistics helpers of the reference's example programs, on the host vector of final values
+  std::vector<float> quart;
+  smmc::update_quartiles(quart, gpu_totals, n);
+  float hmean = 0, hstd = 0, thr = 1200.f;
+  smmc::update_mean_std(hmean, hstd, gpu_totals, n);
+  const long hbelow = smmc::update_count_below_min(thr, gpu_totals, n);
+  std::vector<float> ramp(1000003);
+  for (size_t i = 0; i < ramp.size(); ++i) ramp[i] = float(i);
+  const float ramp_mean = reduce_mean_gpu(ramp, long(ramp.size()));
+  // CSV writers (src/helpers.cpp)
+  std::vector<float> wr = {1.5f, -2.25f}, wv = {1000.f, 1015.f, 992.1625f};
+  write_data_file("dropin_check.csv", wr, wv);
+  write_vector_file("outputs/dropin_check_vec.csv", wv);
+
+  std::printf("{\"quart\": [%.9g, %.9g, %.9g, %.9g, %.9g], \"hmean\": %.9g, \"hstd\": %.9g, \"hbelow\": %ld, \"ramp_mean\": %.9g, ",
+              quart[0], quart[1], quart[2], quart[3], quart[4], hmean, hstd, hbelow, ramp_mean);
+  std::printf("\"n\": %ld, \"gpu_hash\": %" PRIu64 ", \"cpu_hash\": %" PRIu64 ", \"counter_gpu\": %ld, \"seen_mid\": %ld, "
               "\"n_means\": %zu, \"mean0\": %.9g, \"var0\": %.9g, \"threw\": %s, \"rows_ok\": %s, \"keep_hash\": %" PRIu64 ", "
               "\"mu\": [%.9g, %.9g, %.9g, %.9g], \"mu_long_same\": %s, \"update_fund\": %.9g, "
               "\"gauss_hash\": %" PRIu64 ", \"sum_count\": %" PRIu64 ", \"sum_mean\": %.17g, \"sum_below\": %" PRIu64 ", \"hist_total\": %" PRIu64 ", "

@@ -20,6 +20,7 @@ def built():
     ("benchmark_mc_gpu_reduceBlock", "usage: benchmark_mc_gpu_reduceBlock <n_gpus> <n_months> <n_simulations>"),
     ("benchmark_mc_cpu_v2", "usage: visualize_returns <n_months> <n_simulations>"),
     ("benchmark_mc_cpu", "usage: visualize_returns <n_months> <n_simulations>"),
+    ("benchmark_reduce_mean", "usage: compute_avg <n>"),
 ])
 def test_usage_and_exit_code(prog, usage):
     r = subprocess.run([os.path.join(BIN, prog)], capture_output=True, text=True, cwd=ROOT)

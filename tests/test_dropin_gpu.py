@@ -54,6 +54,16 @@ def test_cpp_dropin_matches_python_path_and_oracle(built, oracle, table):
     assert d["sum_count"] == n == d["hist_total"] and d["sum_below"] == g["stats"].below
     assert d["sum_mean"] == pytest.approx(g["stats"].sum / n, rel=1e-12)
     assert d["bundled"] == 1127 and d["sample_hist"] == 17 and d["sample_gauss"] == 9
+    # statistics helpers (examples/visualize_returns_cpu_v2.cpp:83-138) and reduce_mean_gpu
+    assert np.array_equal(np.array(d["quart"], dtype=np.float32), oracle.quartiles(want))
+    w64 = want.astype(np.float64)
+    assert d["hmean"] == pytest.approx(w64.mean(), rel=1e-6) and d["hstd"] == pytest.approx(w64.std(), rel=1e-5)
+    assert d["hbelow"] == int((want < 1200.0).sum())
+    ramp = np.arange(1000003, dtype=np.float32)
+    assert np.float32(d["ramp_mean"]) == np.float32(np.float32(ramp.astype(np.float64).sum()) / np.float32(ramp.size))
+    # CSV writers keep the reference's text format (src/helpers.cpp:18-39)
+    assert open(os.path.join(ROOT, "outputs", "dropin_check.csv")).read() == "Returns,,1.5,-2.25,\nValues,1000,1015,992.162,"
+    assert open(os.path.join(ROOT, "outputs", "dropin_check_vec.csv")).read() == "1000,1015,992.162,"
 
 
 def _run(prog, *args, env=None):
@@ -88,5 +98,7 @@ def test_other_clis_run(built):
     assert r.returncode == 0 and re.search(r"All 100000 simulation done in", r.stdout)
     r = _run("benchmark_mc_cpu", 360, 20000)
     assert r.returncode == 0 and re.search(r"All 20000 simulation done in", r.stdout)
+    r = _run("benchmark_reduce_mean", 5000000)
+    assert r.returncode == 0 and "mean_cpu: 2499999.50 | mean_gpu: 2499999.50" in r.stdout
     r = _run("benchmark_mc_gpu", 1, 360, 5000, env={"SMMC_TABLE": "/nonexistent.csv"})
     assert r.returncode == 0 and "bundled SYNTHETIC table (1127 entries)" in r.stdout
