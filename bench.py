@@ -39,6 +39,11 @@ VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock 
 # VALU work per path-period of paths_kernel's inner loop, from the gfx950 ISA
 # (tools/isa_loop_count.py): instructions, and issue units where a
 # plain VALU op = 1 and multi-cycle ones carry their measured cost (mad_u64 2.29, ...)
+# HBM bytes per launch of paths_kernel from the PMC passes committed in
+# profiles/r01/pmc_summary.txt (WRITE_SIZE KiB + 2 x FETCH_SIZE KiB: the gfx950 read
+# counter tallies 128-byte requests at 64 bytes), measured on the default workload only
+# (1e8 paths, outputs=all): bench.py cannot run rocprofv3 on itself.
+PMC_TRAFFIC_BYTES = {"gaussian": (421446 + 2 * 134) * 1024, "table": (429119 + 2 * 97) * 1024}
 VALU_INSTS_PER_STEP = {"gaussian": 131 / 4, "table": 96 / 8}
 VALU_UNITS_PER_STEP = {"gaussian": 40.1, "table": 17.7}
 
@@ -190,6 +195,8 @@ def main():
         k_avg_s = kernel_ms / 1e3 / max(launches, 1)
         bytes_per_launch = 4.0 * n if want_final else 0.0
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        default_workload = n == PATHS_PER_GPU and args.periods == N_PERIODS and args.outputs == "all"
+        traffic = float(PMC_TRAFFIC_BYTES[args.mode]) if default_workload else None
         insts, units = VALU_INSTS_PER_STEP[args.mode], VALU_UNITS_PER_STEP[args.mode]
         valu_ach = n * args.periods * insts / k_avg_s if k_avg_s > 0 else 0.0
         valu_w = n * args.periods * units / k_avg_s if k_avg_s > 0 else 0.0
@@ -205,7 +212,7 @@ def main():
                        "parallelism": f"path-range shards x{world}, one RCCL all_gather of the stats record per step"
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "paths_kernel", "kernel_ms": k_avg_s * 1e3, "bytes_per_launch": bytes_per_launch,
                          "note": "VALU-bound kernel: 4 B of HBM traffic per 360-period path by construction; "
                                  "see valu"},
