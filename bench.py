@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--paths-per-gpu", type=int, default=PATHS_PER_GPU)
     ap.add_argument("--periods", type=int, default=N_PERIODS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL (the real multi-GPU run); gloo lets several ranks rehearse on ONE GPU")
     ap.add_argument("--outputs", choices=["all", "final", "stats"], default="all",
                     help="all = final values + block means + statistics (configs[1]); final = final values only; "
                          "stats = statistics only (no per-path HBM write)")
@@ -132,13 +134,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % max(torch.cuda.device_count(), 1) if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     table = load_table()
-    eng = S.Engine(local_rank)
+    eng = S.Engine(device)
     eng.set_table(table)
     mode = S.MODE_GAUSSIAN if args.mode == "gaussian" else S.MODE_TABLE
     n = args.paths_per_gpu

@@ -33,6 +33,8 @@ def gather_stats_records(record, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return [record.cpu().numpy().tobytes()]
+    if dist.get_backend(group) == "gloo" and record.is_cuda:
+        record = record.cpu()  # gloo (CPU rehearsals of the N > 1 path) gathers host tensors
     gathered = torch.empty(world * record.numel(), dtype=torch.uint8, device=record.device)
     dist.all_gather_into_tensor(gathered, record.contiguous(), group=group)
     raw = gathered.cpu().numpy().tobytes()
