@@ -123,8 +123,8 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out);
 void smmc_engine_destroy(smmc_engine *e);
 
 /* Uploads the historical-returns table (percent units, host memory).  Replaces
- * the H2D table copies at src/simulations.cu:382,451,525,617.  Asynchronous on
- * the engine stream; the host array may be reused on return. */
+ * the H2D table copies at src/simulations.cu:382,451,525,617.  Waits for work already
+ * enqueued on the engine stream; the host array may be reused on return. */
 int smmc_engine_set_table(smmc_engine *e, const float *returns_percent, uint32_t n);
 
 /* Enqueues one simulation on the engine stream and returns without waiting.

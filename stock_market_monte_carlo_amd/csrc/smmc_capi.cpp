@@ -210,7 +210,7 @@ int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float 
   }
   if (grid > 0) {
     const size_t lds = smmc::paths_lds_bytes(a.table_len, d_stats ? s->n_bins : 0u);
-    if (lds + 1024 > e->max_lds)
+    if (lds + 2048 > e->max_lds)
       return fail(SMMC_ERR_INVALID, "table + histogram need %zu bytes of LDS, device allows %zu", lds, e->max_lds);
     int rc = timing_begin(e);
     if (rc) return rc;
@@ -287,7 +287,8 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     const long v = std::strtol(env, nullptr, 10);
     if (v >= 1 && v <= 4096) e->keepdata_blocks_per_cu = static_cast<uint32_t>(v);
   }
-  e->max_lds = prop.sharedMemPerBlock;
+  // dynamic LDS a launch may ask for: the kernels opt in above the 64 KiB default (CDNA4: 160 KiB per CU)
+  e->max_lds = std::max<size_t>(prop.sharedMemPerBlock, 128u * 1024u);
   if (stream != SMMC_STREAM_NEW) {
     e->stream = static_cast<hipStream_t>(stream);  // NULL = the default stream
   } else {

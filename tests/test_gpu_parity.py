@@ -177,6 +177,22 @@ def test_large_table_uses_the_sparse_schedule(eng, oracle):
         eng.set_table(load_table())
 
 
+def test_maximum_table_and_histogram(eng, oracle):
+    """SMMC_MAX_TABLE entries (64 KiB of LDS) with SMMC_MAX_BINS buckets: above the default
+    64 KiB dynamic-LDS limit, so the launch has to opt in."""
+    from stock_market_monte_carlo_amd import MODE_TABLE
+    from conftest import load_table
+    rng = np.random.default_rng(12)
+    big = rng.normal(0.05, 1.0, 16384).astype(np.float32)
+    eng.set_table(big)
+    try:
+        r, st, o = _run_both(eng, oracle, big, MODE_TABLE, 2000, 50, n_bins=4096, lo=0.0, hi=3000.0)
+        assert np.array_equal(r.final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32))
+        assert np.array_equal(st.hist, o["hist"])
+    finally:
+        eng.set_table(load_table())
+
+
 def test_table_of_one_entry_is_deterministic_compounding(eng, oracle):
     from stock_market_monte_carlo_amd import Engine, MODE_TABLE
     from conftest import load_table
