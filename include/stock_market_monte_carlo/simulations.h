@@ -13,8 +13,13 @@
 #ifndef SMMC_DROPIN_SIMULATIONS_H
 #define SMMC_DROPIN_SIMULATIONS_H
 
+// <chrono>, <iostream>, <random>, <vector>: the reference header includes them
+// (simulations.h:1-4) and its callers rely on that; <atomic>, <string> it gets from fmt.
 #include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <iostream>
+#include <random>
 #include <string>
 #include <vector>
 

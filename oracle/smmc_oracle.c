@@ -17,7 +17,10 @@
  *       calls at src/simulations.cpp:245-247) against the system libstdc++ 11.4
  *       through oracle/pin/pin_libstdcxx.cpp -> tests/golden/libstdcxx_*.json,
  *       and the ISO C++ known answer (10000th output of mt19937() == 4123659995);
- *     - Philox4x32-10 against the published Random123 known-answer vectors.
+ *     - Philox4x32-10 against the published Random123 known-answer vectors;
+ *     - the statistics record (sum, mean, below-count) against update_mean_std /
+ *       update_count_below_min compiled from the reference's examples/benchmark_mc_gpu.cpp
+ *       (oracle/Makefile target _ref; tests/test_ref_callers_cpu.py).
  *   The compounding arithmetic itself is three IEEE-754 binary32 operations
  *   restated from src/simulations.cpp:14-16.
  *

@@ -102,3 +102,25 @@ def test_other_clis_run(built):
     assert r.returncode == 0 and "mean_cpu: 2499999.50 | mean_gpu: 2499999.50" in r.stdout
     r = _run("benchmark_mc_gpu", 1, 360, 5000, env={"SMMC_TABLE": "/nonexistent.csv"})
     assert r.returncode == 0 and "bundled SYNTHETIC table (1127 entries)" in r.stdout
+
+
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "benchmark_mc_cpu_v2")),
+                    reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_reference_programs_compiled_unmodified_run_on_the_drop_in():
+    """examples/benchmark_mc_cpu_v2.cpp and examples/benchmark_mc_cpu.cpp of the reference, compiled
+    from its own sources (oracle/Makefile target _ref) against this header and library: the
+    drop-in claim at link level.  (benchmark_mc_gpu*.cpp call std::locale("en_US.UTF-8"), which
+    this image does not have, so they cannot start here with any backend.)"""
+    env = dict(os.environ, SMMC_SEED="7")
+    r = subprocess.run([os.path.join(REF_DIR, "benchmark_mc_cpu_v2"), "360", "2000000"], cwd=ROOT, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "n_periods: 360 | max_n_simulations: 2000000" in r.stdout
+    assert re.search(r"All 2000000 simulation done in [0-9.e+-]+ s!", r.stdout)
+    r = subprocess.run([os.path.join(REF_DIR, "benchmark_mc_cpu"), "360", "100000"], cwd=ROOT, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert re.search(r"All 100000 simulation done in [0-9.e+-]+ s!", r.stdout)
