@@ -107,6 +107,46 @@ def cpu_baseline(table, budget_s=15.0):
                       f"(per-path mt19937 + Lemire + update_fund, OpenMP dynamic blocks of 1000), {dt:.1f} s"}
 
 
+def hbm_bound_kernels(eng, S, final, mode):
+    """The path's HBM-bound neighbours, timed live with HIP events on the
+    engine's stream AFTER the timed region: statistics and exact quartiles of the resident final
+    values (4 B read per value per pass), and keepdata (4 (P+1) B written per path)."""
+    import ctypes as C
+    out = {}
+    n = final.numel()
+
+    def timed(fn, reps):
+        fn()
+        eng.sync()
+        eng.timing(True)
+        for _ in range(reps):
+            fn()
+        ms, k = eng.kernel_ms()
+        eng.timing(False)
+        return ms / max(k, 1)
+
+    ms = timed(lambda: eng.values_stats(final, 1000.0, 100, 0.0, 20000.0), 10)
+    out["values_stats"] = {"bytes_per_launch": 4.0 * n, "kernel_ms": ms, "GBps": 4.0 * n / ms / 1e6,
+                           "frac_of_peak": 4.0 * n / ms / 1e6 / HBM_PEAK_GBS}
+    ms = timed(lambda: eng.quartiles(final), 5)  # 3 histogram passes per call, each timed
+    out["quartiles_radix_pass"] = {"bytes_per_launch": 4.0 * n, "kernel_ms": ms, "GBps": 4.0 * n / ms / 1e6,
+                                   "frac_of_peak": 4.0 * n / ms / 1e6 / HBM_PEAK_GBS}
+    nk, p = 2_000_000, N_PERIODS
+    sim = S.Engine.make_sim(nk, p, mode, SEED)
+    traj, _ = eng.simulate_keepdata(sim, want_final=False)
+    ms = timed(lambda: _lib_keepdata(eng, sim, traj), 5)
+    b = 4.0 * nk * (p + 1)
+    out["keepdata"] = {"bytes_per_launch": b, "kernel_ms": ms, "GBps": b / ms / 1e6, "frac_of_peak": b / ms / 1e6 / HBM_PEAK_GBS,
+                       "n_paths": nk}
+    return out
+
+
+def _lib_keepdata(eng, sim, traj):
+    import ctypes as C
+    from stock_market_monte_carlo_amd import _lib
+    _lib.check(eng._L.smmc_engine_simulate_keepdata(eng._h, C.byref(sim), C.c_void_p(traj.data_ptr()), None))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +227,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    extra = None
+    if rank == 0 and world == 1 and want_final:
+        try:
+            extra = hbm_bound_kernels(eng, S, final, mode)
+        except Exception as ex:  # never lose the headline line to an optional measurement
+            extra = {"error": str(ex)}
+
     stats = None
     if want_stats:
         if world > 1:
@@ -229,6 +276,8 @@ def main():
         if stats is not None:
             out["result"] = {"mean": stats.mean, "std": stats.std, "below_initial": stats.below,
                              "hist_total": int(stats.hist.sum()) + stats.underflow + stats.overflow}
+        if extra is not None:
+            out["hbm_bound_kernels"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table)
         print(json.dumps(out), flush=True)

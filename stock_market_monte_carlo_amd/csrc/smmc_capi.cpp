@@ -592,7 +592,12 @@ int smmc_engine_values_stats(smmc_engine *e, const float *d_values, uint64_t n, 
   a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
   // 16 bytes per lane per iteration; enough workgroups to keep every CU's memory pipe full
   const uint64_t want = (n / 4 + smmc::kBlock - 1) / smmc::kBlock;
-  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min(e->compute_units * 16u, e->max_grid)));
+  uint32_t per_cu = 8;  // 8 x 4 waves: every workgroup resident at once, one round
+  if (const char *env = std::getenv("SMMC_STATS_BLOCKS_PER_CU")) {  // tuning knob
+    const long v = std::strtol(env, nullptr, 10);
+    if (v >= 1 && v <= 64) per_cu = static_cast<uint32_t>(v);
+  }
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min(e->compute_units * per_cu, e->max_grid)));
   if (n) {
     int rc = timing_begin(e);
     if (rc) return rc;
