@@ -121,6 +121,7 @@ int check_sim(const smmc_engine *e, const smmc_sim *s) {
   if (s->n_bins && (!std::isfinite(s->hist_lo) || !std::isfinite(s->hist_hi)))
     return fail(SMMC_ERR_INVALID, "histogram range must be finite");
   if (s->n_paths > (1ull << 62)) return fail(SMMC_ERR_INVALID, "n_paths too large");
+  if (s->n_periods >= (1u << 31)) return fail(SMMC_ERR_INVALID, "n_periods too large");
   return SMMC_OK;
 }
 
@@ -397,6 +398,7 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   int rc = check_sim(e, sim);
   if (rc) return rc;
   if (!d_traj) return fail(SMMC_ERR_INVALID, "d_traj is NULL");
+  if (sim->n_periods >= (1u << 24)) return fail(SMMC_ERR_INVALID, "keepdata supports n_periods < 2^24");
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
   smmc::KernelArgs a = make_args(e, sim);

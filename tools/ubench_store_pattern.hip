@@ -1,0 +1,71 @@
+// ubench_store_pattern.hip -- what HBM write rate does keepdata's access pattern allow?
+// (development tool)  Every wave owns 64 consecutive rows of `row_len` floats and writes them
+//   A: tile by tile, `tile` aligned floats per row per visit (keepdata's pattern), rows 4*row_len B apart
+//   B: row after row, each row start to end (contiguous per wave)
+// Pure stores of a constant: no compute, no LDS.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int TILE>
+__global__ __launch_bounds__(256) void pattern_a(float *out, unsigned long long n_rows, unsigned row_len) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long n_groups = (n_rows + 63) / 64;
+  constexpr int RPS = 64 / TILE;
+  const unsigned sub = lane / TILE, col = lane % TILE;
+  const unsigned long long base_f = reinterpret_cast<uintptr_t>(out) >> 2;
+  for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wave; g < n_groups; g += (unsigned long long)gridDim.x * 4) {
+    const unsigned long long row0 = g * 64;
+    const unsigned n_tiles = (row_len + 2 * (TILE - 1)) / TILE;
+    for (unsigned t = 0; t < n_tiles; ++t) {
+      unsigned long long row_off = (row0 + sub) * row_len;
+      for (unsigned r = 0; r < 64; r += RPS) {
+        const unsigned phi = (unsigned)(base_f + row_off) & (TILE - 1);
+        const unsigned s = t * TILE + col - phi;
+        if (row0 + r + sub < n_rows && s < row_len) out[row_off + s] = 1.0f + s;
+        row_off += (unsigned long long)RPS * row_len;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pattern_b(float *out, unsigned long long n_rows, unsigned row_len) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long n_groups = (n_rows + 63) / 64;
+  for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wave; g < n_groups; g += (unsigned long long)gridDim.x * 4) {
+    const unsigned long long first = g * 64 * row_len;
+    unsigned long long last = (g * 64 + 64) * row_len;
+    if (last > n_rows * row_len) last = n_rows * row_len;
+    for (unsigned long long i = first + lane; i < last; i += 64) out[i] = 1.0f + (float)lane;
+  }
+}
+
+int main(int argc, char **argv) {
+  const unsigned long long n_rows = 4000000;
+  const unsigned row_len = argc > 1 ? atoi(argv[1]) : 361;
+  float *d;
+  CK(hipMalloc(&d, n_rows * row_len * 4ull + 1024));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const double bytes = 4.0 * n_rows * row_len;
+  for (int bpc : {4, 8, 16}) {
+    for (int v = 0; v < 3; ++v) {
+      float ms = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        if (v == 0) hipLaunchKernelGGL(pattern_a<32>, dim3(256 * bpc), dim3(256), 0, 0, d, n_rows, row_len);
+        if (v == 1) hipLaunchKernelGGL(pattern_a<64>, dim3(256 * bpc), dim3(256), 0, 0, d, n_rows, row_len);
+        if (v == 2) hipLaunchKernelGGL(pattern_b, dim3(256 * bpc), dim3(256), 0, 0, d, n_rows, row_len);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      printf("row_len=%u bpc=%d %s: %.3f ms  %.0f GB/s\n", row_len, bpc,
+             v == 0 ? "A tile=32 (128 B aligned pieces per row)" : v == 1 ? "A tile=64 (256 B aligned pieces per row)" : "B contiguous per wave", ms,
+             bytes / ms / 1e6);
+    }
+  }
+  return 0;
+}
