@@ -21,8 +21,11 @@ HEADERS = [os.path.join(CSRC, "smmc_internal.h"), os.path.join(CSRC, "smmc_bm_ta
 # -ffp-contract=off: results must be bit-identical to the CPU oracle; every FMA in
 # the sources is explicit.  Correctly rounded fp32 divide/sqrt is hipcc's default
 # and must stay on.
+# -fno-slp-vectorize: v_pk_fma_f32 issues at the rate of two scalar FMAs on gfx950, and the
+# register-pair moves SLP packing adds are pure overhead in the VALU-bound loops (131 -> 129
+# instructions per 4 Gaussian periods).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math",
+         "-fno-fast-math", "-fno-slp-vectorize",
          "-Wall", "-Wextra", "-Wno-unused-parameter"]
 
 
