@@ -82,7 +82,23 @@ int main(int argc, char **argv) {
   write_data_file("dropin_check.csv", wr, wv);
   write_vector_file("outputs/dropin_check_vec.csv", wv);
 
-  std::printf("{\"quart\": [%.9g, %.9g, %.9g, %.9g, %.9g], \"hmean\": %.9g, \"hstd\": %.9g, \"hbelow\": %ld, \"ramp_mean\": %.9g, ",
+  // two engines at once from two host threads, as the reference's GUI starts them
+  // (examples/visualize_returns_cpu_v2.cpp:185-202), while this thread polls a counter
+  std::vector<float> conc_final(n, 1000.f), conc_keep_final(nk, -1.f);
+  std::vector<std::vector<float>> conc_data(nk);
+  std::atomic<long> ca{0}, cb{0};
+  {
+    std::thread ta([&] { mc_simulations(ca, n, static_cast<unsigned>(periods), 1000.f, table, conc_final); });
+    std::thread tb([&] { mc_simulations_keepdata(cb, nk, static_cast<unsigned>(periods), 1000.f, table, conc_data, conc_keep_final); });
+    while (ca < n || cb < nk) std::this_thread::yield();
+    ta.join();
+    tb.join();
+  }
+  const bool concurrent_ok = fnv(conc_final) == fnv(cpu_final) && fnv(conc_keep_final) == fnv(keep_final) &&
+                             conc_data[nk - 1] == mc_data[nk - 1];
+
+  std::printf("{\"concurrent_ok\": %s, ", concurrent_ok ? "true" : "false");
+  std::printf("\"quart\": [%.9g, %.9g, %.9g, %.9g, %.9g], \"hmean\": %.9g, \"hstd\": %.9g, \"hbelow\": %ld, \"ramp_mean\": %.9g, ",
               quart[0], quart[1], quart[2], quart[3], quart[4], hmean, hstd, hbelow, ramp_mean);
   std::printf("\"n\": %ld, \"gpu_hash\": %" PRIu64 ", \"cpu_hash\": %" PRIu64 ", \"counter_gpu\": %ld, \"seen_mid\": %ld, "
               "\"n_means\": %zu, \"mean0\": %.9g, \"var0\": %.9g, \"threw\": %s, \"rows_ok\": %s, \"keep_hash\": %" PRIu64 ", "

@@ -40,7 +40,7 @@ def test_cpp_dropin_matches_python_path_and_oracle(built, oracle, table):
     want = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, p, n, 4242, table=table))["final"]
     assert d["gpu_hash"] == fnv(want) == d["cpu_hash"]            # both reference signatures, same stream
     assert d["gpu_hash"] == fnv(S.mc_simulations_gpu(n, p, 1000.0, table, seed=4242))
-    assert d["counter_gpu"] == n
+    assert d["counter_gpu"] == n and d["concurrent_ok"]
     cm, cv = oracle.chunk_mean_var(want)
     assert d["n_means"] == (n + 255) // 256
     assert d["mean0"] == pytest.approx(float(cm[0]), rel=1e-6) and d["var0"] == pytest.approx(float(cv[0]), rel=1e-5)
