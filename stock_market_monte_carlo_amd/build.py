@@ -48,11 +48,19 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    # build beside the target and rename over it: a process that has the old library mapped
+    # keeps its inode instead of seeing the file truncated under it
+    tmp = LIB + ".tmp%d" % os.getpid()
     cmd = [hipcc()] + FLAGS + ["-x", "hip", "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-                                "-o", LIB] + srcs
+                                "-o", tmp] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
@@ -69,11 +77,13 @@ def build_cli(force=False, verbose=False):
         src = os.path.join(cli_dir, name)
         exe = os.path.join(out_dir, name[:-4])
         if force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(LIB)):
-            cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + cli_dir, src, "-o", exe,
+            tmp = exe + ".tmp%d" % os.getpid()
+            cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + cli_dir, src, "-o", tmp,
                    "-L" + PKG, "-lsmmc_hip", "-Wl,-rpath,$ORIGIN/..", "-pthread"]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+            os.replace(tmp, exe)
         built.append(exe)
     return built
 
