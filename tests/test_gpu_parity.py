@@ -265,6 +265,24 @@ def test_full_size_properties(eng, table):
     assert np.array_equal(tail.view(np.uint32), O.counter_mc(op)["final"].view(np.uint32))
 
 
+def test_more_than_2_to_32_paths_in_one_launch(eng, oracle, table):
+    """Statistics only (no 17 GB result array): 64-bit path counts and ids inside one launch."""
+    from stock_market_monte_carlo_amd import Engine, MODE_TABLE
+    n = (1 << 32) + 12345
+    sim = Engine.make_sim(n, 8, MODE_TABLE, 31, n_bins=64, hist_lo=500.0, hist_hi=1500.0)
+    r = eng.simulate(sim, want_final=False, want_stats=True)
+    st = eng.read_stats(r.stats_raw)
+    assert st.count == n and int(st.hist.sum()) + st.underflow + st.overflow == n
+    # the last 1000 paths of that range, simulated on their own, agree with the oracle
+    tail = eng.simulate(Engine.make_sim(1000, 8, MODE_TABLE, 31, first_path=n - 1000)).final.cpu().numpy()
+    o = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 8, 1000, 31, first_path=n - 1000, table=table))
+    assert np.array_equal(tail.view(np.uint32), o["final"].view(np.uint32))
+    # mean of 8 periods of the table's mean return, within 5 standard errors
+    m = float(np.mean(1.0 + table.astype(np.float64) / 100.0))
+    sd = float(np.std(np.log1p(table.astype(np.float64) / 100.0))) * np.sqrt(8) * 1000 * m ** 8
+    assert st.mean == pytest.approx(1000.0 * m ** 8, abs=5 * sd / np.sqrt(n) + 0.05)
+
+
 def test_distribution_matches_reference_cpu_engine(eng, oracle, table):
     """Distribution-level parity with the reference CPU algorithm (engine R: mt19937 +
     Lemire + update_fund, src/simulations.cpp:240-252).  Different generators, same law:
