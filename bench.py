@@ -44,8 +44,8 @@ VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock 
 # counter tallies 128-byte requests at 64 bytes), measured on the default workload only
 # (1e8 paths, outputs=all): bench.py cannot run rocprofv3 on itself.
 PMC_TRAFFIC_BYTES = {"gaussian": (421446 + 2 * 134) * 1024, "table": (429119 + 2 * 97) * 1024}
-VALU_INSTS_PER_STEP = {"gaussian": 129 / 4, "table": 96 / 8}
-VALU_UNITS_PER_STEP = {"gaussian": 39.1, "table": 17.7}
+VALU_INSTS_PER_STEP = {"gaussian": 122 / 4, "table": 96 / 8}
+VALU_UNITS_PER_STEP = {"gaussian": 37.8, "table": 17.7}
 
 
 def load_table():

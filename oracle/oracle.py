@@ -132,6 +132,13 @@ def philox4x32_10(ctr, key):
     return out
 
 
+def box_muller_scaled(ua, ub, scale, shift):
+    a = C.c_float()
+    b = C.c_float()
+    lib().orc_box_muller_scaled(C.c_uint32(ua), C.c_uint32(ub), C.c_float(scale), C.c_float(shift), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def box_muller(ua, ub):
     a = C.c_float()
     b = C.c_float()

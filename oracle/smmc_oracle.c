@@ -211,29 +211,30 @@ static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
  * kernels compile the identical numbers). */
 #include "smmc_bm_tables.inc"
 
-/* Radius r = sqrt(-2 ln U), U = (2 ua + 1) / 2^33, without log or sqrt: U is binned
- * geometrically from the end it is nearer to (side 0: U < 1/2 by U, side 1: by 1 - U),
- * 32 octaves x 16 sub-intervals per side, one cubic per bin in x in [-0.5, 0.5).
- * Integer steps, then three fmaf: bit-reproducible on any IEEE machine. */
+/* Radius r = sqrt(-2 ln U) without log or sqrt.  w = ua ^ (ua >>a 31) is the distance of the
+ * uniform from the end of (0,1) it is nearer to (side 0: U < 1/2, measured from 0; side 1:
+ * from 1); f = (float)(2 w + 1) rounds it to binary32, and U (side 0) or 1 - U (side 1) is
+ * f / 2^33.  The exponent of f picks one of 33 octaves, its top four mantissa bits one of 16
+ * sub-intervals, the remaining 19 bits x in [-0.5, 0.5); one cubic per bin, three fmaf.
+ * An integer-to-float conversion, integer steps and single IEEE operations: bit-reproducible. */
 ORC_API float orc_bm_radius(uint32_t ua) {
   uint32_t mask = (uint32_t)((int32_t)ua >> 31); /* all ones when U >= 1/2 */
-  uint32_t w = ua ^ mask;                        /* distance from the nearer end, < 2^31 */
-  uint32_t w1 = (w << 1) | 1u;                   /* 2 w + 1: odd, in [1, 2^32) */
-  uint32_t c = (uint32_t)__builtin_clz(w1);      /* octave */
-  uint32_t m = w1 << c;                          /* normalised: bit 31 set */
-  uint32_t entry = (mask & 512u) + (c << 4) + ((m >> 27) & 15u);
-  float x = u2f(0x3f800000u | ((m >> 4) & 0x007fffffu)) - 1.5f;
+  uint32_t w1 = ((ua ^ mask) << 1) | 1u;         /* 2 w + 1: odd, in [1, 2^32) */
+  uint32_t bits = f2u((float)w1);                /* round to nearest even, exponent 127 .. 159 */
+  uint32_t entry = (mask & 528u) + (bits >> 19) - (127u << 4); /* 528 = 33 octaves x 16 */
+  float x = u2f(0x3f800000u | ((bits << 4) & 0x007ffff0u)) - 1.5f;
   const float *k = smmc_bm_radius[entry];
   return fmaf(fmaf(fmaf(k[3], x, k[2]), x, k[1]), x, k[0]);
 }
 
-/* Box-Muller on two 32-bit words: ua -> radius (above), ub -> angle theta = 2 pi ub / 2^32
+/* Box-Muller on two 32-bit words, scaled: ua -> radius (above), ub -> angle theta = 2 pi ub / 2^32
  * = 2 pi i / 256 + delta with i = (ub + 2^23) >> 24 and delta = sext24(ub) * 2 pi / 2^32,
  * |delta| <= pi/256: (cos, sin)(2 pi i / 256) from the table, rotated by
  * sin(delta) = delta (1 - delta^2/6), cos(delta) = 1 - delta^2/2 (errors < 1e-9).
- *   z_cos = r * cos(theta), z_sin = r * sin(theta). */
-ORC_API void orc_box_muller(uint32_t ua, uint32_t ub, float *z_cos, float *z_sin) {
-  float r = orc_bm_radius(ua);
+ * Returns the two draws  fma(r * scale, cos(theta), shift)  and  fma(r * scale, sin(theta), shift):
+ * N(shift, scale) variates; scale = 1, shift = 0 gives the standard normals themselves. */
+ORC_API void orc_box_muller_scaled(uint32_t ua, uint32_t ub, float scale, float shift, float *d_cos, float *d_sin) {
+  float rs = orc_bm_radius(ua) * scale;
   uint32_t i = (ub + 0x00800000u) >> 24;
   int32_t d = (int32_t)(ub << 8) >> 8; /* low 24 bits, sign-extended */
   float delta = (float)d * 0x1.921fb6p-30f;
@@ -243,8 +244,12 @@ ORC_API void orc_box_muller(uint32_t ua, uint32_t ub, float *z_cos, float *z_sin
   float ci = smmc_bm_trig[i][0], si = smmc_bm_trig[i][1];
   float ct = fmaf(-si, sd, ci * cd);
   float st = fmaf(ci, sd, si * cd);
-  *z_cos = r * ct;
-  *z_sin = r * st;
+  *d_cos = fmaf(rs, ct, shift);
+  *d_sin = fmaf(rs, st, shift);
+}
+
+ORC_API void orc_box_muller(uint32_t ua, uint32_t ub, float *z_cos, float *z_sin) {
+  orc_box_muller_scaled(ua, ub, 1.0f, 0.0f, z_cos, z_sin);
 }
 
 typedef struct {
@@ -319,10 +324,8 @@ static void path_returns_block(const orc_params *p, uint64_t path, uint32_t blk,
       out[j] = p->table[idx[j]];
     }
   } else {
-    float z[4];
-    orc_box_muller(u[0], u[1], &z[0], &z[1]);
-    orc_box_muller(u[2], u[3], &z[2], &z[3]);
-    for (int j = 0; j < 4; j++) out[j] = fmaf(p->gauss_std, z[j], p->gauss_mean);
+    orc_box_muller_scaled(u[0], u[1], p->gauss_std, p->gauss_mean, &out[0], &out[1]);
+    orc_box_muller_scaled(u[2], u[3], p->gauss_std, p->gauss_mean, &out[2], &out[3]);
   }
 }
 
@@ -474,8 +477,10 @@ ORC_API uint64_t orc_div100_mismatches(uint32_t bits_lo, uint32_t bits_hi, uint3
 ORC_API double orc_bm_radius_scan(uint64_t lo, uint64_t hi, uint64_t stride) {
   double worst = 0;
   for (uint64_t a = lo; a < hi; a += stride) {
-    double u = (2.0 * (double)a + 1.0) * 0x1p-33;
-    double ref = a < 0x80000000ull ? sqrt(-2.0 * log(u)) : sqrt(-2.0 * log1p(-(2.0 * (double)(0xFFFFFFFFull - a) + 1.0) * 0x1p-33));
+    /* the radius is defined on the ROUNDED distance fl(2 w + 1) */
+    uint32_t wv = a < 0x80000000ull ? (uint32_t)a : (uint32_t)(0xFFFFFFFFull - a);
+    double u = (double)(float)((wv << 1) | 1u) * 0x1p-33;
+    double ref = a < 0x80000000ull ? sqrt(-2.0 * log(u)) : sqrt(-2.0 * log1p(-u));
     double err = fabs((double)orc_bm_radius((uint32_t)a) - ref);
     if (err > worst) worst = err;
   }

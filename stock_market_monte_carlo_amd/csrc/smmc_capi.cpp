@@ -306,7 +306,7 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     return fail(SMMC_ERR_HIP, "hipMalloc(partials) failed: %s", hipGetErrorString(err));
   }
   // Box-Muller tables: radius cubics then (cos, sin) pairs, as the kernels stage them
-  static_assert(sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig) == 18432, "table layout");
+  static_assert(sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig) == (1056 * 4 + 256 * 2) * 4, "table layout");
   if (smmc::bm_tables_bytes() != sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig)) {
     smmc_engine_destroy(e);
     return fail(SMMC_ERR_INVALID, "Box-Muller table size mismatch between host and kernels");

@@ -3,6 +3,7 @@ oracle's scanners: the shortcuts themselves are re-stated there with fmaf()."""
 import struct
 
 import numpy as np
+import pytest
 
 
 def bits(f):
@@ -21,8 +22,9 @@ def test_div100_shortcut_is_exact_on_its_whole_domain(oracle):
 
 
 def test_box_muller_radius_table_accuracy(oracle):
-    """r = sqrt(-2 ln((2 ua + 1) / 2^33)) from the piecewise-cubic table: within one
-    binary32 ulp of r (4.8e-7 at the 6.76-sigma end) over a dense sweep of all octaves."""
+    """r = sqrt(-2 ln U) from the piecewise-cubic table, U taken from fl(2 w + 1) / 2^33 (the
+    distance from the nearer end, rounded to binary32): within one binary32 ulp of r (4.8e-7 at
+    the 6.76-sigma end) over a dense sweep of all octaves."""
     assert oracle.bm_radius_scan(0, 2 ** 32, 499) < 6e-7
     assert oracle.bm_radius_scan(0, 1 << 20, 1) < 6e-7                   # deepest tail, every value
     assert oracle.bm_radius_scan((1 << 32) - (1 << 20), 1 << 32, 1) < 6e-7  # U -> 1 end (sqrt singularity)
@@ -36,7 +38,7 @@ def test_box_muller_tables_identical_in_oracle_and_product():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     a = open(os.path.join(root, "oracle", "smmc_bm_tables.inc")).read()
     b = open(os.path.join(root, "stock_market_monte_carlo_amd", "csrc", "smmc_bm_tables.inc")).read()
-    assert a == b and "SMMC_BM_RADIUS_ENTRIES 1024" in a
+    assert a == b and "SMMC_BM_RADIUS_ENTRIES 1056" in a
 
 
 def test_box_muller_moments_and_accuracy(oracle):
@@ -50,6 +52,10 @@ def test_box_muller_moments_and_accuracy(oracle):
     assert np.abs(z[:, 1] - r * np.sin(th)).max() < 2e-6
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
     # extremes of the input words stay finite and bounded
+    # the scaled form the kernels use: fma(r * scale, cos / sin, shift)
+    zc, zs = oracle.box_muller(123456789, 987654321)
+    dc, ds = oracle.box_muller_scaled(123456789, 987654321, 0.83333, 0.5)
+    assert dc == pytest.approx(0.5 + 0.83333 * zc, abs=2e-6) and ds == pytest.approx(0.5 + 0.83333 * zs, abs=2e-6)
     for a, b in [(0, 0), (0xFFFFFFFF, 0xFFFFFFFF), (0, 0x80000000), (0xFFFFFFFF, 0x40000000), (1, 0x3FFFFFFF),
                  (0x7FFFFFFF, 0x007FFFFF), (0x80000000, 0x00800000), (0x12345678, 0xFF800000)]:
         zc, zs = oracle.box_muller(a, b)
