@@ -30,6 +30,33 @@ __global__ __launch_bounds__(256) void pattern_a(float *out, unsigned long long 
   }
 }
 
+// C: keepdata WITHOUT per-lane phase: tile t of every row is the 32 floats [1 + 32 t, 33 + 32 t)
+// of that row, wherever they fall (each piece straddles two lines; the leading part completes the
+// line the previous tile left partial).  `spin` emulates the compute between two tiles of a wave
+// and `lds_bytes` (dynamic LDS) limits the waves per CU: does L2 merge the partial lines when the
+// in-flight footprint (waves x 64 rows x 128 B) fits?
+__global__ __launch_bounds__(256) void pattern_c(float *out, unsigned long long n_rows, unsigned row_len, int spin) {
+  extern __shared__ float lds[];
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long n_groups = (n_rows + 63) / 64;
+  const unsigned sub = lane / 32, col = lane % 32;
+  float acc = 1.0f + lane;
+  for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wave; g < n_groups; g += (unsigned long long)gridDim.x * 4) {
+    const unsigned long long row0 = g * 64;
+    const unsigned n_tiles = (row_len + 31) / 32;
+    for (unsigned t = 0; t < n_tiles; ++t) {
+      for (int i = 0; i < spin; ++i) acc = acc * 1.0000001f + 1e-7f;  // "compute"
+      unsigned long long row_off = (row0 + sub) * row_len;
+      const unsigned s = t * 32 + col;
+      for (unsigned r = 0; r < 64; r += 2) {
+        if (row0 + r + sub < n_rows && s < row_len) out[row_off + s] = acc;
+        row_off += 2ull * row_len;
+      }
+    }
+  }
+  if (acc == 12345.678f) lds[threadIdx.x] = acc;
+}
+
 __global__ __launch_bounds__(256) void pattern_b(float *out, unsigned long long n_rows, unsigned row_len) {
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long n_groups = (n_rows + 63) / 64;
@@ -65,6 +92,19 @@ int main(int argc, char **argv) {
       printf("row_len=%u bpc=%d %s: %.3f ms  %.0f GB/s\n", row_len, bpc,
              v == 0 ? "A tile=32 (128 B aligned pieces per row)" : v == 1 ? "A tile=64 (256 B aligned pieces per row)" : "B contiguous per wave", ms,
              bytes / ms / 1e6);
+    }
+  }
+  for (int lds_kb : {8, 19, 39, 79}) {     // 160 KiB / lds -> 20(cap 8), 8, 4, 2 workgroups per CU
+    for (int spin : {0, 2000, 8000}) {
+      float ms = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(pattern_c, dim3(256 * 16), dim3(256), lds_kb * 1024, 0, d, n_rows, row_len, spin);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      printf("row_len=%u C unaligned 128 B pieces, lds=%d KiB/wg spin=%d: %.3f ms  %.0f GB/s\n", row_len, lds_kb, spin, ms, bytes / ms / 1e6);
     }
   }
   return 0;
