@@ -70,7 +70,7 @@ struct smmc_engine {
   hipStream_t copy_stream = nullptr;  // lazily created, simulate_to_host only
   uint32_t compute_units = 0;
   uint32_t max_grid = 0;
-  uint32_t keepdata_blocks_per_cu = 16;
+  uint32_t keepdata_blocks_per_cu = 0;  // 0: as many keepdata workgroups as are resident
   size_t max_lds = 0;
 
   float *d_table = nullptr;  // 100.0f + r
@@ -404,22 +404,35 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   smmc::KernelArgs a = make_args(e, sim);
   a.d_traj = d_traj;
   a.d_final = d_final;
-  const uint64_t n_chunks = (sim->n_paths + smmc::kBlock - 1) / smmc::kBlock;
-  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid));
-  if (grid == 0) return SMMC_OK;
-  int tile = 32;  // columns per LDS tile (32 | 64); 32 measured faster (3.1 vs 2.6 TB/s)
-  if (const char *env = std::getenv("SMMC_KEEPDATA_TILE")) {  // tuning knob, results do not depend on it
+  if (sim->n_paths == 0) return SMMC_OK;
+  // tuning knobs, results do not depend on them: columns per LDS tile (16 | 32), waves per
+  // workgroup, workgroups per CU.  Defaults measured with tools/kd_ab.py: 32 columns (16 writes
+  // half lines), 4 waves (larger workgroups stay in phase and ran 5-15 % slower), grid = what is
+  // resident (a wave strides over its 64-path chunks).
+  int tile = 32;
+  if (const char *env = std::getenv("SMMC_KEEPDATA_TILE")) {
     const long v = std::strtol(env, nullptr, 10);
-    if (v == 32 || v == 64) tile = static_cast<int>(v);
+    if (v == 16 || v == 32) tile = static_cast<int>(v);
   }
-  while (tile > 32 && smmc::keepdata_lds_bytes(a.table_len, tile) > e->max_lds) tile /= 2;
-  const size_t lds = smmc::keepdata_lds_bytes(a.table_len, tile);
-  if (lds > e->max_lds)
-    return fail(SMMC_ERR_INVALID, "keepdata needs %zu bytes of LDS, device allows %zu", lds, e->max_lds);
-  const uint32_t kgrid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->compute_units * e->keepdata_blocks_per_cu));
+  const size_t lds_cu = 160u * 1024u;
+  const size_t fixed = smmc::keepdata_lds_bytes(a.table_len, tile, 0);
+  const size_t per_wave = smmc::keepdata_lds_bytes(a.table_len, tile, 1) - fixed;
+  const int fit = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 16)) : 0;
+  if (fit < 1) return fail(SMMC_ERR_INVALID, "keepdata: the table leaves no LDS for a tile");
+  int waves = std::min(fit, 4);
+  if (const char *env = std::getenv("SMMC_KEEPDATA_WAVES")) {
+    const long v = std::strtol(env, nullptr, 10);
+    if (v >= 1 && v <= fit) waves = static_cast<int>(v);
+  }
+  const size_t lds = smmc::keepdata_lds_bytes(a.table_len, tile, waves);
+  const uint64_t n_wave_chunks = (sim->n_paths + 63) / 64;
+  const uint32_t resident = static_cast<uint32_t>(std::max<size_t>(lds_cu / lds, 1));
+  const uint32_t per_cu = e->keepdata_blocks_per_cu ? e->keepdata_blocks_per_cu : resident;
+  const uint32_t kgrid = static_cast<uint32_t>(
+      std::min<uint64_t>((n_wave_chunks + waves - 1) / waves, static_cast<uint64_t>(e->compute_units) * per_cu));
   rc = timing_begin(e);
   if (rc) return rc;
-  SMMC_HIP(smmc::launch_keepdata(a, !fast_div_is_safe(e, sim), tile, kgrid, e->stream));
+  SMMC_HIP(smmc::launch_keepdata(a, !fast_div_is_safe(e, sim), tile, waves, kgrid, e->stream));
   return timing_end(e);
 }
 

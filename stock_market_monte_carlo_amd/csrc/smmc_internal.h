@@ -77,11 +77,12 @@ hipError_t launch_paths(const KernelArgs &a, bool exact_div, uint32_t grid, size
                         hipStream_t stream);
 hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, smmc_stats *d_stats,
                            uint32_t n_bins, hipStream_t stream);
-hipError_t launch_keepdata(const KernelArgs &a, bool exact_div, int tile, uint32_t grid, hipStream_t stream);
+hipError_t launch_keepdata(const KernelArgs &a, bool exact_div, int tile, int waves, uint32_t grid,
+                           hipStream_t stream);
 hipError_t launch_selftest(uint32_t lo, uint32_t hi, unsigned long long *d_count, uint32_t grid,
                            hipStream_t stream);
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins);
-size_t keepdata_lds_bytes(uint32_t table_len, int tile);
+size_t keepdata_lds_bytes(uint32_t table_len, int tile, int waves);
 size_t bm_tables_bytes();
 
 }  // namespace smmc

@@ -223,6 +223,45 @@ def test_keepdata_trajectories_bit_exact(eng, oracle, table, mode_name):
                               traj[n - 1].cpu().numpy().view(np.uint32))
 
 
+def test_keepdata_at_any_base_alignment_and_zero_periods(eng, oracle, table):
+    """The C ABI takes any 4-byte aligned d_traj: the row phases follow the base address.  And
+    n_periods = 0 is one column of initial capital."""
+    import ctypes as C
+    import torch
+    from stock_market_monte_carlo_amd import Engine, MODE_TABLE, _lib
+    for shift in (1, 2, 3, 5, 31):
+        for n, p in ((200, 360), (129, 64), (70, 33)):
+            sim = Engine.make_sim(n, p, MODE_TABLE, SEED, first_path=3)
+            buf = torch.full((n * (p + 1) + 64,), -1.0, dtype=torch.float32, device="cuda")
+            view = buf[shift:shift + n * (p + 1)]
+            _lib.check(eng._L.smmc_engine_simulate_keepdata(eng._h, C.byref(sim), C.c_void_p(view.data_ptr()), None))
+            eng.sync()
+            o = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, p, n, SEED, first_path=3, table=table), want_traj=True)
+            got = buf.cpu().numpy()
+            assert np.array_equal(got[shift:shift + n * (p + 1)].view(np.uint32), o["traj"].reshape(-1).view(np.uint32)), (shift, n, p)
+            assert np.all(got[:shift] == -1.0) and np.all(got[shift + n * (p + 1):] == -1.0)  # nothing outside
+    traj, final = eng.simulate_keepdata(Engine.make_sim(300, 0, MODE_TABLE, SEED))
+    assert traj.shape == (300, 1) and bool((traj == 1000.0).all()) and bool((final == 1000.0).all())
+
+
+@pytest.mark.parametrize("knobs", [{"SMMC_KEEPDATA_TILE": "16"}, {"SMMC_KEEPDATA_WAVES": "1"},
+                                   {"SMMC_KEEPDATA_WAVES": "7"}, {"SMMC_KEEPDATA_WAVES": "16"},
+                                   {"SMMC_KEEPDATA_TILE": "16", "SMMC_KEEPDATA_WAVES": "9"}])
+def test_keepdata_tuning_knobs_do_not_change_results(eng, oracle, table, knobs, monkeypatch):
+    """Tile width and workgroup size are read from the environment per call; every setting writes
+    the same bits."""
+    from stock_market_monte_carlo_amd import Engine
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for mode_name, mode in _modes().items():
+        for n, p in ((700, 360), (257, 64), (130, 31), (4097, 70), (333, 129)):
+            sim = Engine.make_sim(n, p, mode, SEED, first_path=11)
+            traj, final = eng.simulate_keepdata(sim)
+            o = oracle.counter_mc(oracle.make_params(mode, p, n, SEED, first_path=11, table=table), want_traj=True)
+            assert np.array_equal(traj.cpu().numpy().view(np.uint32), o["traj"].view(np.uint32)), (knobs, mode_name, n, p)
+            assert np.array_equal(final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32))
+
+
 def test_simulate_to_host_pipeline_matches_device_path(eng, table):
     """More than one 16 Mi-path chunk through the overlapped D2H pipeline."""
     from stock_market_monte_carlo_amd import Engine, MODE_TABLE

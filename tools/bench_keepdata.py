@@ -11,7 +11,7 @@ for mode, name in ((S.MODE_TABLE, "table"), (S.MODE_GAUSSIAN, "gaussian")):
         sim = S.Engine.make_sim(n, p, mode, 7)
         traj, fin = e.simulate_keepdata(sim); e.sync()
         e.timing(True)
-        for _ in range(5):
+        for _ in range(20):  # short kernels: the first few launches after idle run slower
             e._L.smmc_engine_simulate_keepdata(e._h, __import__("ctypes").byref(sim), __import__("ctypes").c_void_p(traj.data_ptr()), None)
         ms, k = e.kernel_ms(); e.timing(False)
         b = 4.0 * n * (p + 1)
