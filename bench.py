@@ -131,10 +131,10 @@ def hbm_bound_kernels(eng, S, final, mode):
     ms = timed(lambda: eng.quartiles(final), 5)  # 3 histogram passes per call, each timed
     out["quartiles_radix_pass"] = {"bytes_per_launch": 4.0 * n, "kernel_ms": ms, "GBps": 4.0 * n / ms / 1e6,
                                    "frac_of_peak": 4.0 * n / ms / 1e6 / HBM_PEAK_GBS}
-    nk, p = 2_000_000, N_PERIODS
+    nk, p = 4_000_000, N_PERIODS
     sim = S.Engine.make_sim(nk, p, mode, SEED)
     traj, _ = eng.simulate_keepdata(sim, want_final=False)
-    ms = timed(lambda: _lib_keepdata(eng, sim, traj), 5)
+    ms = timed(lambda: _lib_keepdata(eng, sim, traj), 20)
     b = 4.0 * nk * (p + 1)
     out["keepdata"] = {"bytes_per_launch": b, "kernel_ms": ms, "GBps": b / ms / 1e6, "frac_of_peak": b / ms / 1e6 / HBM_PEAK_GBS,
                        "n_paths": nk}
