@@ -41,6 +41,22 @@ __device__ __forceinline__ float wave_max(float v) {
 
 constexpr int kWaves = kBlock / 64;
 
+// Streams the float4 body of an array through f, grid-wide: two ADJACENT 16-byte loads in flight
+// per lane (a wave reads 2 KiB contiguous).  Measured on 1e9 values against the alternatives
+// (A/B builds of this loop on one box): two loads a grid apart 5.0-5.5 TB/s, this 5.4-5.7, nontemporal
+// loads the same within 2 %, one load per iteration 3.4-5.7, four adjacent loads 3.7-3.9; a bare
+// read-and-add kernel reaches 6.2-6.4 TB/s on this chip (tools/ubench_read.hip).
+template <typename F>
+__device__ __forceinline__ void stream_float4(const float4 *body, uint64_t n4, uint64_t gtid, uint64_t gsize, F &&f) {
+  const uint64_t n8 = n4 >> 1;
+  for (uint64_t j = gtid; j < n8; j += gsize) {
+    const float4 q0 = body[2 * j], q1 = body[2 * j + 1];
+    f(q0);
+    f(q1);
+  }
+  if ((n4 & 1u) && gtid == 0) f(body[n4 - 1]);
+}
+
 struct Acc {
   double sum = 0.0, sumsq = 0.0;
   uint32_t count = 0, below = 0, under = 0, over = 0;  // a lane sees < 2^32 values per launch
@@ -97,25 +113,12 @@ __global__ __launch_bounds__(kBlock) void values_stats_kernel(const ValuesArgs k
   if (gtid < head) take<kHist>(a, k.values[gtid], k, lds_hist);
   const float4 *body = reinterpret_cast<const float4 *>(k.values + head);
   const uint64_t n4 = (k.n - head) >> 2;
-  uint64_t i = gtid;
-  for (; i + gsize < n4; i += 2 * gsize) {  // two independent 16-byte loads in flight per lane
-    const float4 q0 = body[i], q1 = body[i + gsize];
-    take<kHist>(a, q0.x, k, lds_hist);
-    take<kHist>(a, q0.y, k, lds_hist);
-    take<kHist>(a, q0.z, k, lds_hist);
-    take<kHist>(a, q0.w, k, lds_hist);
-    take<kHist>(a, q1.x, k, lds_hist);
-    take<kHist>(a, q1.y, k, lds_hist);
-    take<kHist>(a, q1.z, k, lds_hist);
-    take<kHist>(a, q1.w, k, lds_hist);
-  }
-  if (i < n4) {
-    const float4 q = body[i];
+  stream_float4(body, n4, gtid, gsize, [&](const float4 &q) {
     take<kHist>(a, q.x, k, lds_hist);
     take<kHist>(a, q.y, k, lds_hist);
     take<kHist>(a, q.z, k, lds_hist);
     take<kHist>(a, q.w, k, lds_hist);
-  }
+  });
   const uint64_t tail0 = head + (n4 << 2);
   if (tail0 + gtid < k.n) take<kHist>(a, k.values[tail0 + gtid], k, lds_hist);  // < 4 elements
 
@@ -215,25 +218,12 @@ __global__ __launch_bounds__(kRadixBlock) void radix_hist_kernel(const float *va
   if (gtid < head) radix_take<kPass>(order_key(values[gtid]), n_groups, gprefix, lds_hist);
   const float4 *body = reinterpret_cast<const float4 *>(values + head);
   const uint64_t n4 = (n - head) >> 2;
-  uint64_t i = gtid;
-  for (; i + gsize < n4; i += 2 * gsize) {  // two independent 16-byte loads in flight per lane
-    const float4 v0 = body[i], v1 = body[i + gsize];
-    radix_take<kPass>(order_key(v0.x), n_groups, gprefix, lds_hist);
-    radix_take<kPass>(order_key(v0.y), n_groups, gprefix, lds_hist);
-    radix_take<kPass>(order_key(v0.z), n_groups, gprefix, lds_hist);
-    radix_take<kPass>(order_key(v0.w), n_groups, gprefix, lds_hist);
-    radix_take<kPass>(order_key(v1.x), n_groups, gprefix, lds_hist);
-    radix_take<kPass>(order_key(v1.y), n_groups, gprefix, lds_hist);
-    radix_take<kPass>(order_key(v1.z), n_groups, gprefix, lds_hist);
-    radix_take<kPass>(order_key(v1.w), n_groups, gprefix, lds_hist);
-  }
-  if (i < n4) {
-    const float4 v = body[i];
+  stream_float4(body, n4, gtid, gsize, [&](const float4 &v) {
     radix_take<kPass>(order_key(v.x), n_groups, gprefix, lds_hist);
     radix_take<kPass>(order_key(v.y), n_groups, gprefix, lds_hist);
     radix_take<kPass>(order_key(v.z), n_groups, gprefix, lds_hist);
     radix_take<kPass>(order_key(v.w), n_groups, gprefix, lds_hist);
-  }
+  });
   const uint64_t tail0 = head + (n4 << 2);
   if (tail0 + gtid < n) radix_take<kPass>(order_key(values[tail0 + gtid]), n_groups, gprefix, lds_hist);
   __syncthreads();
