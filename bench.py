@@ -102,9 +102,17 @@ def cpu_baseline(table, budget_s=15.0):
             break
         n = int(n * min(max(budget_s / max(dt, 1e-3), 1.5), 20.0))
         n -= n % 1000
+    # the same engine on ONE thread (SURVEY 8d asks for both figures): ~3 s
+    n1 = max(1000, int(n / dt * 3.0 / max(used, 1)))
+    n1 -= n1 % 1000
+    t0 = time.perf_counter()
+    O.ref_mc_simulations(n1, N_PERIODS, 1000.0, table, 12345, n_threads=1)
+    dt1 = time.perf_counter() - t0
     return {"value": n / dt, "unit": "paths/s", "cores": used, "kind": "port",
+            "single_thread_value": n1 / dt1,
             "sample": f"{n} paths x {N_PERIODS} periods, table mode (T={table.size}), oracle engine R "
-                      f"(per-path mt19937 + Lemire + update_fund, OpenMP dynamic blocks of 1000), {dt:.1f} s"}
+                      f"(per-path mt19937 + Lemire + update_fund, OpenMP dynamic blocks of 1000, deterministic "
+                      f"seeds: no per-path std::random_device), {dt:.1f} s; single thread: {n1} paths, {dt1:.1f} s"}
 
 
 def hbm_bound_kernels(eng, S, final, mode):
