@@ -11,7 +11,8 @@ knobs = sorted({k for v in variants for k in v})
 e = S.Engine(0); e.set_table(table)
 for mode_name in os.environ.get("KD_MODES", "table,gaussian").split(","):
     mode = S.MODE_GAUSSIAN if mode_name == "gaussian" else S.MODE_TABLE
-    for n, p in ((4_000_000, 360), (1_500_000, 1000), (16_000_000, 63)):
+    shapes = [tuple(int(x) for x in sh.split("x")) for sh in os.environ.get("KD_SHAPES", "4000000x360,1500000x1000,16000000x63").split(",")]
+    for n, p in shapes:
         sim = S.Engine.make_sim(n, p, mode, 7)
         traj = torch.empty(n * (p + 1), dtype=torch.float32, device="cuda")
         times = [[] for _ in variants]
