@@ -322,6 +322,39 @@ def test_more_than_2_to_32_paths_in_one_launch(eng, oracle, table):
     assert st.mean == pytest.approx(1000.0 * m ** 8, abs=5 * sd / np.sqrt(n) + 0.05)
 
 
+@pytest.mark.parametrize("mode_name", ["table", "gaussian"])
+def test_keepdata_full_size_properties(eng, oracle, table, mode_name, monkeypatch):
+    """keepdata at benchmark size (4e6 paths x 360 periods, 5.8 GB on the device): properties that
+    need no oracle run over everything, the oracle checks sampled rows."""
+    import torch
+    from stock_market_monte_carlo_amd import Engine
+    mode = _modes()[mode_name]
+    n, p, first = 4_000_000, 360, 123_456_789_000  # path ids past 2^32
+    sim = Engine.make_sim(n, p, mode, SEED, first_path=first)
+    traj, final = eng.simulate_keepdata(sim)
+    assert bool((traj[:, 0] == 1000.0).all())                                   # values[0] = initial capital
+    assert torch.equal(traj[:, p].contiguous().view(torch.int32), final.view(torch.int32))  # last column = final value
+    # the same bits as the kernel that keeps only the final values
+    only_final = eng.simulate(sim).final
+    assert torch.equal(only_final.view(torch.int32), final.view(torch.int32))
+    checksum = int(traj.view(torch.int32).to(torch.int64).sum().item())
+    # sampled rows against the oracle's trajectory of that path (first, last, wave and chunk edges, random)
+    rng = np.random.default_rng(5)
+    rows = sorted({0, 1, 63, 64, 255, 256, n - 1, n - 64, n - 65, *rng.integers(0, n, 40).tolist()})
+    op = oracle.make_params(mode, p, n, SEED, first_path=first, table=table)
+    got = traj[torch.tensor(rows, device=traj.device)].cpu().numpy()
+    for k, r in enumerate(rows):
+        want = oracle.many_updates(1000.0, oracle.counter_path_returns(op, first + r), p)
+        assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), r
+    del traj, only_final
+    # tuning knobs: same checksum of all bits
+    monkeypatch.setenv("SMMC_KEEPDATA_WAVES", "12")
+    monkeypatch.setenv("SMMC_KEEPDATA_TILE", "16")
+    traj2, final2 = eng.simulate_keepdata(sim)
+    assert int(traj2.view(torch.int32).to(torch.int64).sum().item()) == checksum
+    assert torch.equal(final2.view(torch.int32), final.view(torch.int32))
+
+
 def test_distribution_matches_reference_cpu_engine(eng, oracle, table):
     """Distribution-level parity with the reference CPU algorithm (engine R: mt19937 +
     Lemire + update_fund, src/simulations.cpp:240-252).  Different generators, same law:
