@@ -407,10 +407,10 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   if (sim->n_paths == 0) return SMMC_OK;
   // tuning knobs, results do not depend on them: columns per LDS tile (16 | 32), waves per
   // workgroup, workgroups per CU.  Defaults measured with tools/kd_ab.py: 32 columns (16 writes
-  // half lines); 4 waves for long rows (workgroups of 8 ran 1-5 % slower, 3 / 5 / 6 waves -- SIMDs
-  // unevenly filled -- 5-25 % slower) but one 12-wave workgroup per CU for rows under 192 values,
-  // which are mostly general column groups (7-18 % faster there, within +-3 % above); grid = what
-  // is resident (a wave strides over its 64-path chunks).
+  // half lines); table mode 4 waves, three workgroups per CU (8 or 12 waves 1-5 % slower, 3 / 5 /
+  // 6 waves -- SIMDs unevenly filled -- 5-25 % slower); Gaussian mode, where the Box-Muller tables
+  // take 18.9 KB of every workgroup's LDS, one 12-wave workgroup per CU (2-15 % faster than two of
+  // 4); grid = what is resident (a wave strides over its 64-path chunks).
   int tile = 32;
   if (const char *env = std::getenv("SMMC_KEEPDATA_TILE")) {
     const long v = std::strtol(env, nullptr, 10);
@@ -419,10 +419,9 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   const size_t lds_cu = 160u * 1024u;
   const size_t fixed = smmc::keepdata_lds_bytes(a.table_len, tile, 0);
   const size_t per_wave = smmc::keepdata_lds_bytes(a.table_len, tile, 1) - fixed;
-  const int fit = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 16)) : 0;
+  const int fit = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 12)) : 0;
   if (fit < 1) return fail(SMMC_ERR_INVALID, "keepdata: the table leaves no LDS for a tile");
-  const bool short_rows = sim->n_periods + 1u < 192u;
-  int waves = short_rows ? (fit >= 12 ? 12 : fit >= 8 ? 8 : std::min(fit, 4)) : std::min(fit, 4);
+  int waves = sim->mode == SMMC_MODE_TABLE ? std::min(fit, 4) : (fit >= 12 ? 12 : fit >= 8 ? 8 : std::min(fit, 4));
   if (const char *env = std::getenv("SMMC_KEEPDATA_WAVES")) {
     const long v = std::strtol(env, nullptr, 10);
     if (v >= 1 && v <= fit) waves = static_cast<int>(v);

@@ -245,7 +245,7 @@ def test_keepdata_at_any_base_alignment_and_zero_periods(eng, oracle, table):
 
 
 @pytest.mark.parametrize("knobs", [{"SMMC_KEEPDATA_TILE": "16"}, {"SMMC_KEEPDATA_WAVES": "1"},
-                                   {"SMMC_KEEPDATA_WAVES": "7"}, {"SMMC_KEEPDATA_WAVES": "16"},
+                                   {"SMMC_KEEPDATA_WAVES": "7"}, {"SMMC_KEEPDATA_WAVES": "12"}, {"SMMC_KEEPDATA_WAVES": "4"},
                                    {"SMMC_KEEPDATA_TILE": "16", "SMMC_KEEPDATA_WAVES": "9"}])
 def test_keepdata_tuning_knobs_do_not_change_results(eng, oracle, table, knobs, monkeypatch):
     """Tile width and workgroup size are read from the environment per call; every setting writes
@@ -348,7 +348,7 @@ def test_keepdata_full_size_properties(eng, oracle, table, mode_name, monkeypatc
         assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), r
     del traj, only_final
     # tuning knobs: same checksum of all bits
-    monkeypatch.setenv("SMMC_KEEPDATA_WAVES", "12")
+    monkeypatch.setenv("SMMC_KEEPDATA_WAVES", "8")
     monkeypatch.setenv("SMMC_KEEPDATA_TILE", "16")
     traj2, final2 = eng.simulate_keepdata(sim)
     assert int(traj2.view(torch.int32).to(torch.int64).sum().item()) == checksum
