@@ -143,7 +143,8 @@ int smmc_engine_simulate(smmc_engine *e, const smmc_sim *sim, float *d_final, fl
 /* Same, but keeps every trajectory: d_traj is n_paths x (n_periods + 1) floats,
  * path-major (row i = the `values` vector of path i, values[0] = initial capital)
  * -- mc_data of mc_simulations_keepdata (src/simulations.cpp:139-186).  d_final
- * may be NULL. */
+ * may be NULL.  Any 4-byte aligned d_traj; n_periods < 2^24 (SMMC_ERR_INVALID
+ * otherwise). */
 int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_traj, float *d_final);
 
 /* Blocks until everything enqueued on the engine stream has finished. */

@@ -398,6 +398,8 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   int rc = check_sim(e, sim);
   if (rc) return rc;
   if (!d_traj) return fail(SMMC_ERR_INVALID, "d_traj is NULL");
+  if ((reinterpret_cast<uintptr_t>(d_traj) | reinterpret_cast<uintptr_t>(d_final)) & 3u)
+    return fail(SMMC_ERR_INVALID, "d_traj and d_final must be 4-byte aligned");
   if (sim->n_periods >= (1u << 24)) return fail(SMMC_ERR_INVALID, "keepdata supports n_periods < 2^24");
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);

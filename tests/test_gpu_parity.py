@@ -242,6 +242,11 @@ def test_keepdata_at_any_base_alignment_and_zero_periods(eng, oracle, table):
             assert np.all(got[:shift] == -1.0) and np.all(got[shift + n * (p + 1):] == -1.0)  # nothing outside
     traj, final = eng.simulate_keepdata(Engine.make_sim(300, 0, MODE_TABLE, SEED))
     assert traj.shape == (300, 1) and bool((traj == 1000.0).all()) and bool((final == 1000.0).all())
+    # rejected before any launch: a pointer that is not 4-byte aligned, too many periods
+    sim = Engine.make_sim(10, 5, MODE_TABLE, SEED)
+    assert eng._L.smmc_engine_simulate_keepdata(eng._h, C.byref(sim), C.c_void_p(traj.data_ptr() + 2), None) == -1  # SMMC_ERR_INVALID
+    sim = Engine.make_sim(10, 1 << 24, MODE_TABLE, SEED)
+    assert eng._L.smmc_engine_simulate_keepdata(eng._h, C.byref(sim), C.c_void_p(traj.data_ptr()), None) == -1
 
 
 @pytest.mark.parametrize("knobs", [{"SMMC_KEEPDATA_TILE": "16"}, {"SMMC_KEEPDATA_WAVES": "1"},
