@@ -134,7 +134,7 @@ int smmc_engine_set_table(smmc_engine *e, const float *returns_percent, uint32_t
  *   d_chunk_mean  ceil(n_paths / SMMC_CHUNK) floats, mean of each 256-path chunk
  *   d_chunk_var   same length, population variance of each chunk
  *                 (means/variances of the reduceBlock kernel, src/simulations.cu:240-246)
- *   d_stats       smmc_stats_bytes(sim->n_bins) bytes, packed statistics record
+ *   d_stats       smmc_stats_bytes(sim->n_bins) bytes, packed statistics record, 8-byte aligned
  * Replaces mc_simulations_gpu_launcher / _reduceBlock_launcher
  * (src/simulations.cu:345-473). */
 int smmc_engine_simulate(smmc_engine *e, const smmc_sim *sim, float *d_final, float *d_chunk_mean,

@@ -389,6 +389,10 @@ int smmc_engine_simulate(smmc_engine *e, const smmc_sim *sim, float *d_final, fl
                          float *d_chunk_var, void *d_stats) {
   int rc = check_sim(e, sim);
   if (rc) return rc;
+  if ((reinterpret_cast<uintptr_t>(d_final) | reinterpret_cast<uintptr_t>(d_chunk_mean) |
+       reinterpret_cast<uintptr_t>(d_chunk_var)) & 3u)
+    return fail(SMMC_ERR_INVALID, "d_final, d_chunk_mean and d_chunk_var must be 4-byte aligned");
+  if (reinterpret_cast<uintptr_t>(d_stats) & 7u) return fail(SMMC_ERR_INVALID, "d_stats must be 8-byte aligned");
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
   return enqueue_simulation(e, sim, d_final, d_chunk_mean, d_chunk_var, d_stats);
@@ -594,6 +598,7 @@ int smmc_engine_values_stats(smmc_engine *e, const float *d_values, uint64_t n, 
   if (n_bins && (!(hist_lo < hist_hi) || !std::isfinite(hist_lo) || !std::isfinite(hist_hi)))
     return fail(SMMC_ERR_INVALID, "histogram range must be finite with lo < hi");
   if (reinterpret_cast<uintptr_t>(d_values) & 3u) return fail(SMMC_ERR_INVALID, "d_values must be 4-byte aligned");
+  if (reinterpret_cast<uintptr_t>(d_stats) & 7u) return fail(SMMC_ERR_INVALID, "d_stats must be 8-byte aligned");
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
   SMMC_HIP(hipMemsetAsync(d_stats, 0, smmc_stats_bytes(n_bins), e->stream));
