@@ -169,10 +169,11 @@ def test_large_table_uses_the_sparse_schedule(eng, oracle):
             r, st, o = _run_both(eng, oracle, big, MODE_TABLE, 3001, p, n_bins=20, lo=0.0, hi=3000.0)
             assert np.array_equal(r.final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32)), p
             assert np.array_equal(st.hist, o["hist"])
-        sim = Engine.make_sim(200, 70, MODE_TABLE, SEED, first_path=5)
-        traj, _ = eng.simulate_keepdata(sim)
-        o = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 70, 200, SEED, first_path=5, table=big), want_traj=True)
-        assert np.array_equal(traj.cpu().numpy().view(np.uint32), o["traj"].view(np.uint32))
+        for n, p in ((200, 70), (1500, 200), (700, 63), (333, 360), (129, 31)):
+            sim = Engine.make_sim(n, p, MODE_TABLE, SEED, first_path=5)
+            traj, _ = eng.simulate_keepdata(sim)
+            o = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, p, n, SEED, first_path=5, table=big), want_traj=True)
+            assert np.array_equal(traj.cpu().numpy().view(np.uint32), o["traj"].view(np.uint32)), (n, p)
     finally:
         eng.set_table(load_table())
 
@@ -189,6 +190,11 @@ def test_maximum_table_and_histogram(eng, oracle):
         r, st, o = _run_both(eng, oracle, big, MODE_TABLE, 2000, 50, n_bins=4096, lo=0.0, hi=3000.0)
         assert np.array_equal(r.final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32))
         assert np.array_equal(st.hist, o["hist"])
+        # keepdata next to a 64 KiB table: fewer waves fit a workgroup
+        from stock_market_monte_carlo_amd import Engine
+        traj, _ = eng.simulate_keepdata(Engine.make_sim(900, 100, MODE_TABLE, SEED))
+        o = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 100, 900, SEED, table=big), want_traj=True)
+        assert np.array_equal(traj.cpu().numpy().view(np.uint32), o["traj"].view(np.uint32))
     finally:
         eng.set_table(load_table())
 
