@@ -267,9 +267,11 @@ def main():
             "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.mode} returns, {args.periods} periods x {n:.0e} paths per GPU, "
-                                   f"outputs={args.outputs} (BASELINE configs[1])",
+            "config": {"workload": f"{args.mode} returns, {args.periods} periods x {n:.3g} paths per GPU, "
+                                   f"outputs={args.outputs}"
+                                   + (f" (BASELINE configs[{1 if args.mode == 'gaussian' else 2}])" if default_workload else ""),
                        "paths_per_gpu": n, "n_periods": args.periods, "mode": args.mode, "seed": hex(SEED),
+                       "divide": ("fast", "exact", "checked")[eng.divide_kind(sim)],
                        "parallelism": f"path-range shards x{world}, one RCCL all_gather of the stats record per step"
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

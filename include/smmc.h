@@ -221,6 +221,17 @@ int smmc_engine_kernel_ms(smmc_engine *e, double *total_ms, uint32_t *launches);
  * IEEE x / 100.0f.  Synchronous. */
 int smmc_engine_selftest(smmc_engine *e, uint32_t bits_lo, uint32_t bits_hi, uint64_t *div_mismatches);
 
+/* Which divide-by-100 a launch of `sim` uses (the result never depends on it): SMMC_DIV_FAST, the
+ * reciprocal-multiply form, when the returns table (or mean +- 7 std), the capital and the number of
+ * periods prove that no path can leave its domain; SMMC_DIV_CHECKED (final-value launches only)
+ * when they do not but a per-block range check with an IEEE-divide rerun of the rare offending path
+ * is possible; SMMC_DIV_EXACT, the IEEE divide, otherwise or with SMMC_FLAG_EXACT_DIV.
+ * keepdata != 0 asks for smmc_engine_simulate_keepdata.  Returns the kind (>= 0) or an error. */
+#define SMMC_DIV_FAST 0
+#define SMMC_DIV_EXACT 1
+#define SMMC_DIV_CHECKED 2
+int smmc_engine_divide_kind(smmc_engine *e, const smmc_sim *sim, int keepdata);
+
 /* Launch geometry the engine will use (workgroups x threads), for reports. */
 int smmc_engine_geometry(smmc_engine *e, uint32_t *grid, uint32_t *block, uint32_t *compute_units);
 

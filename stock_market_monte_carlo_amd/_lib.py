@@ -56,6 +56,8 @@ class Stats(C.Structure):
 
 
 # every symbol include/smmc.h declares: (name, restype, argtypes)
+DIV_FAST, DIV_EXACT, DIV_CHECKED = 0, 1, 2  # smmc_engine_divide_kind
+
 SYMBOLS = [
     ("smmc_update_fund", C.c_float, [C.c_float, C.c_float]),
     ("smmc_many_updates", None, [C.c_void_p, C.c_void_p, C.c_uint32]),
@@ -88,6 +90,7 @@ SYMBOLS = [
      [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("smmc_engine_geometry", C.c_int,
      [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("smmc_engine_divide_kind", C.c_int, [C.c_void_p, C.POINTER(Sim), C.c_int]),
     ("smmc_stats_bytes", C.c_uint64, [C.c_uint32]),
     ("smmc_stats_merge", C.c_int, [C.c_void_p, C.c_void_p]),
 ]

@@ -125,30 +125,51 @@ int check_sim(const smmc_engine *e, const smmc_sim *s) {
   return SMMC_OK;
 }
 
-// The reciprocal-multiply divide is exact for |x| >= 2^-124 (and x = +0); pick it only
-// if no intermediate of any path can leave [2^-100, 2^100] or change sign.
-bool fast_div_is_safe(const smmc_engine *e, const smmc_sim *s) {
-  if (s->flags & SMMC_FLAG_EXACT_DIV) return false;
-  const double cap = s->initial_capital;
-  if (!(cap > 0.0) || !std::isfinite(cap)) return false;
-  double lo_a, hi_a;
+// The reciprocal-multiply divide is exact for every finite |x| >= 2^-124 (and x = +0), x being the
+// product total * a.  Bounds on a = 100 + r for one period: false if there are none.
+bool multiplier_bounds(const smmc_engine *e, const smmc_sim *s, double *lo_a, double *hi_a) {
   if (s->mode == SMMC_MODE_TABLE) {
     if (!e->table_finite) return false;
-    lo_a = e->table_min_a;
-    hi_a = e->table_max_a;
+    *lo_a = e->table_min_a;
+    *hi_a = e->table_max_a;
   } else {
     if (!std::isfinite(s->gauss_mean) || !std::isfinite(s->gauss_std)) return false;
     // |z| <= sqrt(-2 ln 2^-33) * (1 + eps) < 6.8; 7 leaves margin for the roundings
     const double spread = 7.0 * std::fabs(static_cast<double>(s->gauss_std));
-    lo_a = 100.0 + s->gauss_mean - spread - 1e-3;
-    hi_a = 100.0 + s->gauss_mean + spread + 1e-3;
+    *lo_a = 100.0 + s->gauss_mean - spread - 1e-3;
+    *hi_a = 100.0 + s->gauss_mean + spread + 1e-3;
   }
-  if (!(lo_a > 0.0) || !std::isfinite(hi_a)) return false;
+  return *lo_a > 0.0 && std::isfinite(*hi_a);
+}
+
+// Which divide a launch may use (SMMC_DIV_*).  FAST: no product of any path can leave
+// [2^-123, 2^127) or change sign, proven from the bounds, the capital and the number of periods
+// (one bit of margin on each side for the roundings along the way).  CHECKED (paths_kernel only):
+// not provable -- a table with one +42 % month fails for 360 periods -- but a path inside
+// [*chk_lo, *chk_hi] at a Philox-block boundary cannot leave the domain during the next 8 periods,
+// so the kernel tests that window once per block and redoes the rare path that leaves it with the
+// IEEE divide.  EXACT otherwise, or on request.
+int divide_kind(const smmc_engine *e, const smmc_sim *s, bool allow_checked, float *chk_lo, float *chk_hi) {
+  *chk_lo = 0.0f;
+  *chk_hi = 0.0f;
+  if (s->flags & SMMC_FLAG_EXACT_DIV) return SMMC_DIV_EXACT;
+  const double cap = s->initial_capital;
+  if (!(cap > 0.0) || !std::isfinite(cap)) return SMMC_DIV_EXACT;
+  double lo_a, hi_a;
+  if (!multiplier_bounds(e, s, &lo_a, &hi_a)) return SMMC_DIV_EXACT;
   const double p = static_cast<double>(s->n_periods);
-  // after k periods: cap * prod(a/100) (the product total*a is 100x larger: +7 bits)
-  const double up = std::log2(cap) + p * std::max(0.0, std::log2(hi_a / 100.0)) + 7.0;
-  const double dn = std::log2(cap) + p * std::min(0.0, std::log2(lo_a / 100.0)) - 7.0;
-  return up < 100.0 && dn > -100.0;
+  const double grow = std::max(0.0, std::log2(hi_a / 100.0)), shrink = std::max(0.0, -std::log2(lo_a / 100.0));
+  const double top = std::log2(hi_a), bottom = std::min(0.0, std::log2(lo_a));
+  // total after k periods lies in cap * [(lo_a/100)^k, (hi_a/100)^k]; the next product is that times a
+  if (std::log2(cap) + p * grow + top + 1.0 < 127.0 && std::log2(cap) - p * shrink + bottom - 1.0 > -123.0)
+    return SMMC_DIV_FAST;
+  if (!allow_checked) return SMMC_DIV_EXACT;
+  // a block is at most 8 periods: 7 steps to its last total, then one more product
+  const double hi_w = 127.0 - 1.0 - 7.0 * grow - top, lo_w = -123.0 + 1.0 + 7.0 * shrink - bottom;
+  if (!(lo_w + 2.0 < std::log2(cap) && std::log2(cap) < hi_w - 2.0)) return SMMC_DIV_EXACT;
+  *chk_lo = static_cast<float>(std::exp2(lo_w));
+  *chk_hi = static_cast<float>(std::exp2(hi_w));
+  return SMMC_DIV_CHECKED;
 }
 
 smmc::KernelArgs make_args(const smmc_engine *e, const smmc_sim *s) {
@@ -215,7 +236,8 @@ int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float 
       return fail(SMMC_ERR_INVALID, "table + histogram need %zu bytes of LDS, device allows %zu", lds, e->max_lds);
     int rc = timing_begin(e);
     if (rc) return rc;
-    SMMC_HIP(smmc::launch_paths(a, !fast_div_is_safe(e, s), grid, lds, e->stream));
+    const int div = divide_kind(e, s, true, &a.chk_lo, &a.chk_hi);
+    SMMC_HIP(smmc::launch_paths(a, div, grid, lds, e->stream));
     rc = timing_end(e);
     if (rc) return rc;
   }
@@ -440,7 +462,9 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
       std::min<uint64_t>((n_wave_chunks + waves - 1) / waves, static_cast<uint64_t>(e->compute_units) * per_cu));
   rc = timing_begin(e);
   if (rc) return rc;
-  SMMC_HIP(smmc::launch_keepdata(a, !fast_div_is_safe(e, sim), tile, waves, kgrid, e->stream));
+  float unused_lo, unused_hi;
+  const bool exact_div = divide_kind(e, sim, false, &unused_lo, &unused_hi) != SMMC_DIV_FAST;
+  SMMC_HIP(smmc::launch_keepdata(a, exact_div, tile, waves, kgrid, e->stream));
   return timing_end(e);
 }
 
@@ -808,6 +832,13 @@ int smmc_engine_geometry(smmc_engine *e, uint32_t *grid, uint32_t *block, uint32
   if (block) *block = smmc::kBlock;
   if (compute_units) *compute_units = e->compute_units;
   return SMMC_OK;
+}
+
+int smmc_engine_divide_kind(smmc_engine *e, const smmc_sim *sim, int keepdata) {
+  const int rc = check_sim(e, sim);
+  if (rc) return rc;
+  float lo, hi;
+  return divide_kind(e, sim, keepdata == 0, &lo, &hi);
 }
 
 uint64_t smmc_stats_bytes(uint32_t n_bins) { return sizeof(smmc_stats) + sizeof(uint64_t) * n_bins; }

@@ -37,6 +37,7 @@ struct KernelArgs {
   double hist_inv;       // (double)n_bins / ((double)hi - (double)lo), computed on the host
   float below_threshold;
   float *d_traj;         // keepdata only: n_paths x (n_periods + 1), path-major
+  float chk_lo, chk_hi;  // SMMC_DIV_CHECKED only: the window a path must stay in at Philox-block boundaries
 };
 
 // values_stats_kernel arguments (smmc_stats_kernels.hip)
@@ -73,7 +74,8 @@ hipError_t launch_radix_pick(int pass, uint32_t n_ranks, SelectState *st, const 
                              float *d_out, hipStream_t stream);
 
 // Launch wrappers (defined in smmc_kernels.hip).  All asynchronous on `stream`.
-hipError_t launch_paths(const KernelArgs &a, bool exact_div, uint32_t grid, size_t lds_bytes,
+// `div`: SMMC_DIV_* of smmc.h (how a launch divides by 100: simulate_path in smmc_kernels.hip)
+hipError_t launch_paths(const KernelArgs &a, int div, uint32_t grid, size_t lds_bytes,
                         hipStream_t stream);
 hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, smmc_stats *d_stats,
                            uint32_t n_bins, hipStream_t stream);

@@ -223,6 +223,14 @@ class Engine:
                                                         C.byref(mean), C.byref(total)))
         return mean.value, total.value
 
+    def divide_kind(self, sim, keepdata=False):
+        """DIV_FAST / DIV_EXACT / DIV_CHECKED: which divide-by-100 a launch of `sim` uses (results
+        never depend on it)."""
+        rc = self._L.smmc_engine_divide_kind(self._h, C.byref(sim), 1 if keepdata else 0)
+        if rc < 0:
+            _lib.check(rc)
+        return rc
+
     def simulate_keepdata(self, sim, want_final=True):
         torch = self._torch
         n, p = int(sim.n_paths), int(sim.n_periods)

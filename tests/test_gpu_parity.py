@@ -115,6 +115,65 @@ def test_out_of_range_trajectories_take_the_ieee_divide(eng, oracle):
         eng.set_table(load_table())
 
 
+def test_fast_divide_window_edges(eng, oracle):
+    """The host picks the reciprocal-multiply divide while every product total * a stays inside
+    [2^-123, 2^127) and the IEEE divide beyond: both sides of both edges equal the oracle (which
+    always divides), down to subnormal and up to inf results."""
+    from stock_market_monte_carlo_amd import Engine, MODE_TABLE
+    from conftest import load_table
+    try:
+        for ret, periods in ((60.0, (160, 170, 180, 200)), (-60.0, (85, 90, 95, 110))):
+            tab = np.array([ret], dtype=np.float32)
+            eng.set_table(tab)
+            for p in periods:
+                r, st, o = _run_both(eng, oracle, tab, MODE_TABLE, 300, p, cap=1.0, n_bins=8, lo=0.0, hi=1.0e38)
+                assert np.array_equal(r.final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32)), (ret, p)
+                assert np.array_equal(st.hist, o["hist"])
+                traj, _ = eng.simulate_keepdata(Engine.make_sim(70, p, MODE_TABLE, SEED, initial_capital=1.0))
+                ot = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, p, 70, SEED, table=tab, initial_capital=1.0), want_traj=True)
+                assert np.array_equal(traj.cpu().numpy().view(np.uint32), ot["traj"].view(np.uint32)), (ret, p)
+    finally:
+        eng.set_table(load_table())
+
+
+def test_checked_divide_for_tables_that_cannot_be_proven_safe(eng, oracle, table):
+    """A table with a +42 % month cannot be PROVEN to stay in the fast divide's domain over 360
+    periods, yet no path gets there: the engine then runs the fast divide with one range check per
+    Philox block and redoes a path that leaves the window with the IEEE divide.  Same bits as the
+    oracle (which always divides) without offenders, with every second path offending upwards
+    (to inf) and downwards (to subnormals and 0)."""
+    from stock_market_monte_carlo_amd import Engine, MODE_GAUSSIAN, MODE_TABLE, _lib
+    from conftest import load_table
+    assert eng.divide_kind(Engine.make_sim(1000, 360, MODE_TABLE, SEED)) == _lib.DIV_FAST
+    assert eng.divide_kind(Engine.make_sim(1000, 1000, MODE_GAUSSIAN, SEED)) == _lib.DIV_FAST
+    assert eng.divide_kind(Engine.make_sim(1000, 1000, MODE_TABLE, SEED)) == _lib.DIV_CHECKED
+    assert eng.divide_kind(Engine.make_sim(1000, 1000, MODE_TABLE, SEED), keepdata=True) == _lib.DIV_EXACT
+    assert eng.divide_kind(Engine.make_sim(1000, 360, MODE_TABLE, SEED, exact_div=True)) == _lib.DIV_EXACT
+    try:
+        real = table.copy()
+        real[7], real[100] = 42.2, -29.7  # the S&P 500's best and worst months
+        eng.set_table(real)
+        sim = Engine.make_sim(20_000, 360, MODE_TABLE, SEED)
+        assert eng.divide_kind(sim) == _lib.DIV_CHECKED
+        for p in (360, 1000, 7, 8, 9):
+            r, st, o = _run_both(eng, oracle, real, MODE_TABLE, 20_000, p, n_bins=100, lo=0.0, hi=1.0e6)
+            assert np.array_equal(r.final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32)), p
+            assert np.array_equal(st.hist, o["hist"])
+        for tab, cap in (([60.0, -20.0], 2.0 ** 50), ([60.0, -50.0], 2.0 ** -60)):
+            tab = np.array(tab, dtype=np.float32)
+            eng.set_table(tab)
+            for p in (400, 403):
+                assert eng.divide_kind(Engine.make_sim(10, p, MODE_TABLE, SEED, initial_capital=cap)) == _lib.DIV_CHECKED
+                r, st, o = _run_both(eng, oracle, tab, MODE_TABLE, 6000, p, cap=cap, n_bins=16, lo=0.0, hi=1.0e38)
+                got, want = r.final.cpu().numpy(), o["final"]
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tab, p)
+                assert np.array_equal(st.hist, o["hist"])
+                out = np.isinf(want) | (want < 2.0 ** -110) if cap > 1 else (want < 2.0 ** -118)
+                assert 0.1 < out.mean() < 0.9  # the rerun really is exercised, and so is its absence
+    finally:
+        eng.set_table(load_table())
+
+
 def test_histogram_edges_and_single_bin(eng, oracle, table):
     from stock_market_monte_carlo_amd import MODE_TABLE
     # narrow range: most values under/overflow; 1 bin; 4096 bins
