@@ -46,6 +46,7 @@ VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock 
 PMC_TRAFFIC_BYTES = {"gaussian": (421446 + 2 * 134) * 1024, "table": (429119 + 2 * 97) * 1024}
 VALU_INSTS_PER_STEP = {"gaussian": 122 / 4, "table": 96 / 8}
 VALU_UNITS_PER_STEP = {"gaussian": 37.8, "table": 17.7}
+VALU_CHECK_PER_STEP = {"gaussian": 2 / 4, "table": 2 / 8}  # the range-checked divide: two compares per Philox block
 
 
 def load_table():
@@ -259,8 +260,13 @@ def main():
         default_workload = n == PATHS_PER_GPU and args.periods == N_PERIODS and args.outputs == "all"
         traffic = float(PMC_TRAFFIC_BYTES[args.mode]) if default_workload else None
         insts, units = VALU_INSTS_PER_STEP[args.mode], VALU_UNITS_PER_STEP[args.mode]
-        valu_ach = n * args.periods * insts / k_avg_s if k_avg_s > 0 else 0.0
-        valu_w = n * args.periods * units / k_avg_s if k_avg_s > 0 else 0.0
+        kind = eng.divide_kind(sim)
+        if kind == 2:  # checked
+            insts, units = insts + VALU_CHECK_PER_STEP[args.mode], units + VALU_CHECK_PER_STEP[args.mode]
+        elif kind == 1:  # IEEE divide: not counted (28.3 units per period in table mode)
+            insts = units = None
+        valu_ach = n * args.periods * insts / k_avg_s if k_avg_s > 0 and insts else 0.0
+        valu_w = n * args.periods * units / k_avg_s if k_avg_s > 0 and units else 0.0
         out = {
             "metric": "simulated paths/sec at N=360 periods" if args.periods == 360
                       else f"simulated paths/sec at N={args.periods} periods",
@@ -271,7 +277,7 @@ def main():
                                    f"outputs={args.outputs}"
                                    + (f" (BASELINE configs[{1 if args.mode == 'gaussian' else 2}])" if default_workload else ""),
                        "paths_per_gpu": n, "n_periods": args.periods, "mode": args.mode, "seed": hex(SEED),
-                       "divide": ("fast", "exact", "checked")[eng.divide_kind(sim)],
+                       "divide": ("fast", "exact", "checked")[kind],
                        "parallelism": f"path-range shards x{world}, one RCCL all_gather of the stats record per step"
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
