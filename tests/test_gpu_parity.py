@@ -275,7 +275,8 @@ def test_keepdata_trajectories_bit_exact(eng, oracle, table, mode_name):
     from stock_market_monte_carlo_amd import Engine
     mode = _modes()[mode_name]
     for n, p in [(300, 360), (1000, 1), (257, 64), (64, 65), (700, 130), (130, 31), (65, 7), (1, 100),
-                 (500, 63), (500, 62), (129, 95), (3, 200), (64, 127), (4097, 70), (2, 63), (1000, 1000)]:
+                 (500, 63), (500, 62), (129, 95), (3, 200), (64, 127), (4097, 70), (2, 63), (1000, 1000),
+                 (3, (1 << 22) + 5)]:  # the last one: rows too long for 32-bit byte offsets
         sim = Engine.make_sim(n, p, mode, SEED, first_path=11)
         traj, final = eng.simulate_keepdata(sim)
         op = oracle.make_params(mode, p, n, SEED, first_path=11, table=table)
