@@ -1,16 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X Monte-Carlo returns engine.
 
-Metric (BASELINE.json): simulated paths/sec at 360 periods.  One "step" = one pass
-of the hot path over one batch of synthetic input: PATHS_PER_GPU paths x 360 periods
-per GPU, Gaussian returns (BASELINE configs[1]: "Gaussian returns, 360 periods x 1e8
-paths, 1 x MI355X, final-value only + block-reduce mean"), producing the final value
-of every path in HBM, the per-256-path block means/variances and the fused
-statistics record (sum, sum of squares, below-count, 100-bucket histogram).
+Metric (BASELINE.json): simulated paths/sec at 360 periods.  One "step" = one pass of
+the hot path over one batch of synthetic input.  `--config K` selects BASELINE.json's
+`configs[K]`; the default (K = 1) is the configuration the metric is quoted on:
+Gaussian returns, 360 periods x 1e8 paths per GPU, producing the final value of every
+path in HBM, the per-256-path block means/variances and the fused statistics record
+(sum, sum of squares, below-count, 100-bucket histogram).
 
-Multi-GPU (`torchrun`-style launch, one rank per GPU): paths shard by contiguous
-global id ranges (weak scaling: PATHS_PER_GPU each); the only exchange is one RCCL
-all_gather of the ~900-byte statistics record per step, merged in rank order.
+  --config 0  configs[0]  360 x 1e6 paths, Gaussian (the reference's CPU-runnable size)
+  --config 1  configs[1]  360 x 1e8 paths per GPU, Gaussian, final values + block means + statistics  [default]
+  --config 2  configs[2]  360 x 1e8 paths per GPU, historical table staged in LDS
+  --config 3  configs[3]  360 x 1e9 paths IN TOTAL, sharded over the ranks, statistics only,
+                          one RCCL all_gather of the ~900-byte record per step
+  --config 4  configs[4]  1000 x 1e9 paths IN TOTAL, sharded; final values into pinned HOST memory
+                          through the chunked kernel / side-stream D2H pipeline (PCIe inside the
+                          timed region: that IS this configuration's job)
+
+Multi-GPU: one process per GPU.  `python bench.py --gpus N` starts its N ranks itself
+(the parent never touches the GPU; it relays rank 0's JSON line and exits with the
+children's return code); under `python -m torch.distributed.run ... bench.py --gpus N`
+the ranks torchrun made are used as they are.  Paths shard by contiguous global id ranges
+(reference: n_gpus is just an argument, examples/benchmark_mc_gpu.cpp:52-69, split at
+src/simulations.cu:599-607); the only exchange is the statistics record, merged in rank order.
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline      HBM roofline of the dominant kernel (paths_kernel): algorithmic bytes
@@ -18,11 +30,15 @@ Prints ONE JSON line on rank 0.  Extra objects:
                 The kernel is VALU-bound by design, so this fraction is tiny; the
                 `valu` object carries the roof that actually binds.
   cpu_baseline  the reference's CPU algorithm (oracle engine R: mt19937 + Lemire +
-                update_fund, OpenMP hw-1 threads) timed on this host on a bounded sample.
+                update_fund, OpenMP hw-1 threads) timed on this host on a bounded sample,
+                with deterministic seeds (`value`) and as the reference really does it,
+                one std::random_device per path (`as_reference_value`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,17 +52,29 @@ PATHS_PER_GPU = 100_000_000
 SEED = 0x5EED5EED5EED5EED
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock = 7.86e13 lane-ops/s
-# VALU work per path-period of paths_kernel's inner loop, from the gfx950 ISA
-# (tools/isa_loop_count.py): instructions, and issue units where a
-# plain VALU op = 1 and multi-cycle ones carry their measured cost (mad_u64 2.29, ...)
-# HBM bytes per launch of paths_kernel from the PMC passes committed in
-# profiles/r01/pmc_summary.txt (WRITE_SIZE KiB + 2 x FETCH_SIZE KiB: the gfx950 read
-# counter tallies 128-byte requests at 64 bytes), measured on the default workload only
-# (1e8 paths, outputs=all): bench.py cannot run rocprofv3 on itself.
-PMC_TRAFFIC_BYTES = {"gaussian": (421446 + 2 * 134) * 1024, "table": (429119 + 2 * 97) * 1024}
+# VALU instructions per path-period of paths_kernel's inner loop, read off the gfx950 ISA by
+# tools/isa_loop_count.py (tests/test_measurement_cpu.py asserts these equal the built library's).
 VALU_INSTS_PER_STEP = {"gaussian": 122 / 4, "table": 96 / 8}
-VALU_UNITS_PER_STEP = {"gaussian": 37.8, "table": 17.7}
 VALU_CHECK_PER_STEP = {"gaussian": 2 / 4, "table": 2 / 8}  # the range-checked divide: two compares per Philox block
+# HBM bytes per launch measured by the round's rocprofv3 PMC passes (tools/pmc_traffic.py writes it)
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+CONFIGS = {
+    0: dict(mode="gaussian", periods=360, paths_per_gpu=1_000_000, total_paths=None, outputs="all",
+            name="BASELINE configs[0] size on the GPU: Gaussian returns, 360 periods x 1e6 paths"),
+    1: dict(mode="gaussian", periods=360, paths_per_gpu=PATHS_PER_GPU, total_paths=None, outputs="all",
+            name="BASELINE configs[1]: Gaussian returns, 360 periods x 1e8 paths, 1xMI355X, final-value only + "
+                 "block-reduce mean"),
+    2: dict(mode="table", periods=360, paths_per_gpu=PATHS_PER_GPU, total_paths=None, outputs="all",
+            name="BASELINE configs[2]: historical S&P500 monthly returns (LDS-staged table), 360 periods x 1e8 paths, "
+                 "1xMI355X"),
+    3: dict(mode="gaussian", periods=360, paths_per_gpu=None, total_paths=1_000_000_000, outputs="stats",
+            name="BASELINE configs[3]: Gaussian returns, 360 periods x 1e9 paths sharded across the GPUs, RCCL "
+                 "gather of the statistics record (histogram)"),
+    4: dict(mode="gaussian", periods=1000, paths_per_gpu=None, total_paths=1_000_000_000, outputs="host",
+            name="BASELINE configs[4]: Gaussian returns, 1000 periods x 1e9 paths sharded across the GPUs, final "
+                 "values to pinned host memory, D2H overlapped on a side HIP stream"),
+}
 
 
 def load_table():
@@ -86,7 +114,7 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(table, budget_s=15.0):
+def cpu_baseline(table, budget_s=12.0, n_periods=N_PERIODS):
     """Times the oracle's reference-faithful engine (R) -- the checker, used here only as
     the CPU baseline the metric asks for."""
     from oracle import oracle as O
@@ -97,7 +125,7 @@ def cpu_baseline(table, budget_s=15.0):
     n, dt, used = 50_000, 0.0, threads
     while True:  # grow the sample until it is >= 2/3 of the budget of CPU wall time
         t0 = time.perf_counter()
-        _, used = O.ref_mc_simulations(n, N_PERIODS, 1000.0, table, 12345, n_threads=threads)
+        _, used = O.ref_mc_simulations(n, n_periods, 1000.0, table, 12345, n_threads=threads)
         dt = time.perf_counter() - t0
         if dt >= budget_s * 2 / 3 or n >= 200_000_000:
             break
@@ -107,20 +135,39 @@ def cpu_baseline(table, budget_s=15.0):
     n1 = max(1000, int(n / dt * 3.0 / max(used, 1)))
     n1 -= n1 % 1000
     t0 = time.perf_counter()
-    O.ref_mc_simulations(n1, N_PERIODS, 1000.0, table, 12345, n_threads=1)
+    O.ref_mc_simulations(n1, n_periods, 1000.0, table, 12345, n_threads=1)
     dt1 = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "paths/s", "cores": used, "kind": "port",
-            "single_thread_value": n1 / dt1,
-            "sample": f"{n} paths x {N_PERIODS} periods, table mode (T={table.size}), oracle engine R "
-                      f"(per-path mt19937 + Lemire + update_fund, OpenMP dynamic blocks of 1000, deterministic "
-                      f"seeds: no per-path std::random_device), {dt:.1f} s; single thread: {n1} paths, {dt1:.1f} s"}
+    out = {"value": n / dt, "unit": "paths/s", "cores": used, "kind": "port",
+           "single_thread_value": n1 / dt1,
+           "sample": f"{n} paths x {n_periods} periods, table mode (T={table.size}), oracle engine R "
+                     f"(per-path mt19937 + Lemire + update_fund, OpenMP dynamic blocks of 1000, deterministic "
+                     f"seeds: no per-path std::random_device), {dt:.1f} s; single thread: {n1} paths, {dt1:.1f} s"}
+    # variant (i) of SURVEY 8d: as the reference does it, a fresh std::random_device seeding a fresh
+    # mt19937 for EVERY path (src/simulations.cpp:245-247) -- set-up dominated and OS dependent
+    try:
+        nr = max(1000, int(min(n, n / dt * 4.0)))  # ~4 s if it ran at the deterministic rate; it will not
+        nr -= nr % 1000
+        while True:
+            t0 = time.perf_counter()
+            O.asref_mc_simulations(nr, n_periods, 1000.0, table, n_threads=threads)
+            dtr = time.perf_counter() - t0
+            if dtr >= 3.0 or nr >= n:
+                break
+            nr = min(n, int(nr * min(max(4.0 / max(dtr, 1e-3), 1.5), 10.0)))
+            nr -= nr % 1000
+        out["as_reference_value"] = nr / dtr
+        out["as_reference_sample"] = (f"{nr} paths, one std::random_device + mt19937 seeding per path as "
+                                      f"src/simulations.cpp:245-247, {used} threads, {dtr:.1f} s")
+    except Exception as ex:  # the C++ leg is optional: never lose the line to it
+        out["as_reference_value"] = None
+        out["as_reference_sample"] = f"unavailable: {ex}"
+    return out
 
 
 def hbm_bound_kernels(eng, S, final, mode):
     """The path's HBM-bound neighbours, timed live with HIP events on the
     engine's stream AFTER the timed region: statistics and exact quartiles of the resident final
     values (4 B read per value per pass), and keepdata (4 (P+1) B written per path)."""
-    import ctypes as C
     out = {}
     n = final.numel()
 
@@ -156,34 +203,181 @@ def _lib_keepdata(eng, sim, traj):
     _lib.check(eng._L.smmc_engine_simulate_keepdata(eng._h, C.byref(sim), C.c_void_p(traj.data_ptr()), None))
 
 
+def pmc_traffic(mode, n, periods, outputs):
+    """HBM bytes per paths_kernel launch from the rocprofv3 PMC passes committed under profiles/
+    (bench.py cannot run rocprofv3 on itself): (bytes, source) or (None, None) when this workload
+    was not profiled."""
+    try:
+        table = json.load(open(PMC_TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None, None
+    rec = table.get(f"{mode}|{n}|{periods}|{outputs}")
+    if not rec:
+        return None, None
+    return float(rec["bytes"]), rec.get("source")
+
+
+# ---- launching the ranks ---------------------------------------------------------------------
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes, relay rank 0's
+    stdout (the JSON line), return the worst return code.  This parent never initialises the GPU (it
+    has not even imported torch) and nothing here execs: children are ordinary subprocesses."""
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMMC_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    out0 = b""
+    try:
+        deadline = time.time() + float(os.environ.get("SMMC_BENCH_TIMEOUT", "1500"))
+        pending = set(range(n_ranks))
+        failed_at = None
+        while pending:
+            for r in sorted(pending):
+                if r == 0:
+                    try:
+                        o, _ = procs[0].communicate(timeout=0.2)
+                        out0 += o or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    failed_at = failed_at or time.time()
+            if pending and ((failed_at and time.time() - failed_at > 20.0) or time.time() > deadline):
+                rc = rc or 124  # a rank died or the run overran: the others would wait for it forever
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:  # exactly the processes started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+def launch_check(args, world, rank):
+    """CPU rehearsal of the N > 1 control path (no GPU, no kernels): the ranks rendezvous, each builds
+    the statistics record of its shard of `--total-paths` synthetic paths, the product's one
+    all_gather + rank-order merge runs, and rank 0 prints the JSON line."""
+    import torch
+    import torch.distributed as dist
+    from stock_market_monte_carlo_amd import _lib
+    from stock_market_monte_carlo_amd.dist import all_gather_merge_stats, shard_range
+    if world > 1:
+        dist.init_process_group("gloo")
+    n_total = args.total_paths or 10007 * world + 3
+    first, count = shard_range(n_total, world, rank)
+    n_bins = 16
+    hdr = _lib.Stats(count, count // 3, 0, 0, float(count), float(count), 1.0, 1.0, n_bins, 0)
+    hist = np.zeros(n_bins, dtype=np.uint64)
+    hist[rank % n_bins] = count
+    rec = torch.frombuffer(bytearray(bytes(hdr) + hist.tobytes()), dtype=torch.uint8)
+    t0 = time.perf_counter()
+    merged = all_gather_merge_stats(rec) if world > 1 else None
+    dt = time.perf_counter() - t0
+    names = [None] * world
+    if world > 1:
+        dist.all_gather_object(names, f"rank {rank}: cpu (launch check)")
+        assert merged.count == n_total and int(merged.hist.sum()) == n_total, (merged.count, n_total)
+    else:
+        names = ["rank 0: cpu (launch check)"]
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no simulation)", "value": 0.0, "unit": "paths/s", "n_gpus": world,
+                          "ranks": dist.get_world_size() if world > 1 else 1, "backend": "gloo" if world > 1 else "none",
+                          "devices": names, "steps": 0, "warmup": 0, "ms_per_step": dt * 1e3,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": "launch check", "total_paths": n_total},
+                          "launcher": "self" if os.environ.get("SMMC_BENCH_CHILD") else "external"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=["gaussian", "table"], default="gaussian")
-    ap.add_argument("--paths-per-gpu", type=int, default=PATHS_PER_GPU)
-    ap.add_argument("--periods", type=int, default=N_PERIODS)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=1,
+                    help="BASELINE.json configs[K]; explicit flags below override the preset")
+    ap.add_argument("--mode", choices=["gaussian", "table"], default=None)
+    ap.add_argument("--paths-per-gpu", type=int, default=None, help="weak scaling: this many paths on every rank")
+    ap.add_argument("--total-paths", type=int, default=None, help="strong scaling: this many paths sharded over the ranks")
+    ap.add_argument("--periods", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL (the real multi-GPU run); gloo lets several ranks rehearse on ONE GPU")
-    ap.add_argument("--outputs", choices=["all", "final", "stats"], default="all",
+    ap.add_argument("--outputs", choices=["all", "final", "stats", "host"], default=None,
                     help="all = final values + block means + statistics (configs[1]); final = final values only; "
-                         "stats = statistics only (no per-path HBM write)")
+                         "stats = statistics only (no per-path HBM write); host = final values into pinned host "
+                         "memory through the chunked side-stream pipeline (configs[4])")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="CPU-only rehearsal of rank launch + rendezvous + the statistics gather (no GPU work)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    have_ranks = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not have_ranks:
+        # no launcher made our ranks: make them (BEFORE anything in this process touches torch or HIP)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    world = int(os.environ.get("WORLD_SIZE", "1")) if have_ranks else 1
+    rank = int(os.environ.get("RANK", "0")) if have_ranks else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if have_ranks else 0
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher made WORLD_SIZE={world} ranks")
+    if args.launch_check:
+        return launch_check(args, world, rank)
+
+    preset = CONFIGS[args.config]
+    mode_name = args.mode or preset["mode"]
+    periods = args.periods if args.periods is not None else preset["periods"]
+    outputs = args.outputs or preset["outputs"]
+    total_paths, per_gpu = preset["total_paths"], preset["paths_per_gpu"]
+    if args.total_paths is not None:
+        total_paths, per_gpu = args.total_paths, None
+    elif args.paths_per_gpu is not None:
+        total_paths, per_gpu = None, args.paths_per_gpu
+    is_preset = (args.mode is None and args.periods is None and args.outputs is None and args.total_paths is None
+                 and args.paths_per_gpu is None)
 
     import torch
     import torch.distributed as dist
     import stock_market_monte_carlo_amd as S
-    from stock_market_monte_carlo_amd.dist import gather_stats_records
+    from stock_market_monte_carlo_amd.dist import gather_stats_records, shard_range
     from stock_market_monte_carlo_amd.engine import merge_stats_bytes, stats_from_bytes
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    device = local_rank % max(torch.cuda.device_count(), 1) if args.backend == "gloo" else local_rank
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("no MI355X visible: bench.py has no CPU path (use --launch-check for the CPU rehearsal)")
+    if args.backend == "nccl" and world > n_dev:
+        raise SystemExit(f"--gpus {world} with the RCCL backend needs {world} devices, {n_dev} visible "
+                         "(use --backend gloo to rehearse several ranks on one GPU)")
+    device = local_rank % n_dev
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -195,20 +389,34 @@ def main():
     table = load_table()
     eng = S.Engine(device)
     eng.set_table(table)
-    mode = S.MODE_GAUSSIAN if args.mode == "gaussian" else S.MODE_TABLE
-    n = args.paths_per_gpu
-    sim = S.Engine.make_sim(n, args.periods, mode, SEED, first_path=rank * n, initial_capital=1000.0,
+    mode = S.MODE_GAUSSIAN if mode_name == "gaussian" else S.MODE_TABLE
+    if total_paths is not None:  # strong scaling: contiguous id ranges, the remainder kept
+        first, n = shard_range(total_paths, world, rank)
+        n_all = total_paths
+    else:                        # weak scaling
+        first, n = rank * per_gpu, per_gpu
+        n_all = per_gpu * world
+    sim = S.Engine.make_sim(n, periods, mode, SEED, first_path=first, initial_capital=1000.0,
                             gauss_mean=0.5, gauss_std=0.83333, n_bins=100, hist_lo=0.0, hist_hi=20000.0)
-    want_final = args.outputs in ("all", "final")
-    want_chunks = args.outputs == "all"
-    want_stats = args.outputs in ("all", "stats")
+    to_host = outputs == "host"
+    want_final = outputs in ("all", "final")
+    want_chunks = outputs == "all"
+    want_stats = outputs in ("all", "stats")
     final = torch.empty(n, dtype=torch.float32, device=eng.tdevice) if want_final else None
+    host_final = None
+    if to_host:
+        # the caller's result buffer, pinned once outside the timed region as the reference does with
+        # cudaMallocHost (src/simulations.cu:591-592)
+        host_final = torch.empty(n, dtype=torch.float32, pin_memory=True).numpy()
     records = None
 
     def step():
         # the whole per-step job: simulate this rank's shard, then (N > 1) the one RCCL
         # all_gather of the statistics records, merged in rank order on the host
         nonlocal records
+        if to_host:
+            eng.simulate_to_host(sim, out=host_final)
+            return None
         r = eng.simulate(sim, want_final=want_final, want_chunk_stats=want_chunks, want_stats=want_stats, out=final)
         if want_stats:
             records = gather_stats_records(r.stats_raw) if world > 1 else None
@@ -224,6 +432,7 @@ def main():
     barrier()
     eng.timing(True)
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
         last = step()
     barrier()
@@ -231,10 +440,15 @@ def main():
     kernel_ms, launches = eng.kernel_ms()
     eng.timing(False)
 
+    devices = [None] * world
+    mine = f"rank {rank}: cuda:{device} {torch.cuda.get_device_name(device)}"
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=eng.tdevice)
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.tdevice if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        dist.all_gather_object(devices, mine)
+    else:
+        devices = [mine]
 
     extra = None
     if rank == 0 and world == 1 and want_final:
@@ -244,51 +458,66 @@ def main():
             extra = {"error": str(ex)}
 
     stats = None
-    if want_stats:
+    if want_stats and last is not None:
         if world > 1:
             stats = stats_from_bytes(merge_stats_bytes(records))
         else:
             stats = eng.read_stats(last.stats_raw)
-        assert stats.count == n * world, (stats.count, n * world)
+        assert stats.count == n_all, (stats.count, n_all)
 
     if rank == 0:
-        total_paths = n * world * args.steps
-        value = total_paths / dt
-        k_avg_s = kernel_ms / 1e3 / max(launches, 1)
-        bytes_per_launch = 4.0 * n if want_final else 0.0
+        value = n_all * args.steps / dt
+        k_s = kernel_ms / 1e3  # summed kernel time of this rank's launches in the timed region
+        k_avg_s = k_s / max(launches, 1)
+        paths_per_launch = n * args.steps / max(launches, 1)  # host pipeline: one launch per 2^24-path chunk
+        writes_final = want_final or to_host
+        bytes_per_launch = 4.0 * paths_per_launch if writes_final else 0.0
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
-        default_workload = n == PATHS_PER_GPU and args.periods == N_PERIODS and args.outputs == "all"
-        traffic = float(PMC_TRAFFIC_BYTES[args.mode]) if default_workload else None
-        insts, units = VALU_INSTS_PER_STEP[args.mode], VALU_UNITS_PER_STEP[args.mode]
+        traffic, traffic_src = pmc_traffic(mode_name, n, periods, outputs)
+        insts = VALU_INSTS_PER_STEP[mode_name]
         kind = eng.divide_kind(sim)
         if kind == 2:  # checked
-            insts, units = insts + VALU_CHECK_PER_STEP[args.mode], units + VALU_CHECK_PER_STEP[args.mode]
-        elif kind == 1:  # IEEE divide: not counted (28.3 units per period in table mode)
-            insts = units = None
-        valu_ach = n * args.periods * insts / k_avg_s if k_avg_s > 0 and insts else 0.0
-        valu_w = n * args.periods * units / k_avg_s if k_avg_s > 0 and units else 0.0
+            insts = insts + VALU_CHECK_PER_STEP[mode_name]
+        elif kind == 1:  # IEEE divide: not counted
+            insts = None
+        valu_ach = paths_per_launch * periods * insts / k_avg_s if k_avg_s > 0 and insts else 0.0
+        if world == 1:
+            par = "single GPU"
+        elif to_host:
+            par = f"path-range shards x{world}, no collective (each rank streams its shard to its own host buffer)"
+        else:
+            par = f"path-range shards x{world}, one {'RCCL' if args.backend == 'nccl' else 'gloo'} all_gather of the stats record per step"
+        workload = (preset["name"] if is_preset else
+                    f"{mode_name} returns, {periods} periods x "
+                    + (f"{total_paths:.3g} paths in total" if total_paths is not None else f"{per_gpu:.3g} paths per GPU")
+                    + f", outputs={outputs}")
         out = {
-            "metric": "simulated paths/sec at N=360 periods" if args.periods == 360
-                      else f"simulated paths/sec at N={args.periods} periods",
-            "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "simulated paths/sec at N=360 periods" if periods == 360
+                      else f"simulated paths/sec at N={periods} periods",
+            "value": value, "unit": "paths/s", "n_gpus": world, "ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": ("rccl (torch nccl)" if args.backend == "nccl" else "gloo") if world > 1 else "none",
+            "devices": devices, "launcher": "self" if os.environ.get("SMMC_BENCH_CHILD") else
+                                            ("external" if have_ranks else "none"),
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if total_paths is not None else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.mode} returns, {args.periods} periods x {n:.3g} paths per GPU, "
-                                   f"outputs={args.outputs}"
-                                   + (f" (BASELINE configs[{1 if args.mode == 'gaussian' else 2}])" if default_workload else ""),
-                       "paths_per_gpu": n, "n_periods": args.periods, "mode": args.mode, "seed": hex(SEED),
-                       "divide": ("fast", "exact", "checked")[kind],
-                       "parallelism": f"path-range shards x{world}, one RCCL all_gather of the stats record per step"
-                                      if world > 1 else "single GPU"},
+            "config": {"workload": workload, "baseline_config": args.config if is_preset else None,
+                       "paths_rank0": n, "paths_all_ranks": n_all, "n_periods": periods, "mode": mode_name,
+                       "outputs": outputs, "seed": hex(SEED), "divide": ("fast", "exact", "checked")[kind],
+                       "parallelism": par},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "paths_kernel", "kernel_ms": k_avg_s * 1e3, "bytes_per_launch": bytes_per_launch,
-                         "note": "VALU-bound kernel: 4 B of HBM traffic per 360-period path by construction; "
-                                 "see valu"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "paths_kernel", "kernel_ms": k_avg_s * 1e3, "launches": launches,
+                         "bytes_per_launch": bytes_per_launch,
+                         "note": "VALU-bound kernel: 4 B of HBM traffic per path by construction; see valu"},
             "valu": {"bound": "valu-issue", "achieved": valu_ach, "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s",
                      "frac": valu_ach / VALU_PEAK_LANEOPS, "insts_per_path_period": insts,
-                     "issue_weighted_frac": valu_w / VALU_PEAK_LANEOPS, "issue_units_per_path_period": units},
+                     "note": "unweighted: every VALU instruction counted as one 2-clock issue slot"},
         }
+        if to_host:
+            out["host_pipeline"] = {"bytes_to_host_per_step": 4.0 * n, "GBps_rank0": 4.0 * n * args.steps / dt / 1e9,
+                                    "kernel_busy_frac": k_s / dt if dt > 0 else None, "pinned": True}
         if stats is not None:
             out["result"] = {"mean": stats.mean, "std": stats.std, "below_initial": stats.below,
                              "hist_total": int(stats.hist.sum()) + stats.underflow + stats.overflow}

@@ -156,6 +156,34 @@ def ref_mc_simulations(n_paths, n_periods, initial_capital, table, seed0, n_thre
     return out, used
 
 
+_asref = None
+
+
+def asref_mc_simulations(n_paths, n_periods, initial_capital, table, n_threads=0, fixed_seed0=None):
+    """The reference's CPU loop as it really runs (src/simulations.cpp:240-252): a fresh
+    std::random_device + mt19937 per path, real libstdc++ classes (oracle/asref_cpu.cpp).  Not
+    reproducible unless fixed_seed0 is given, in which case it must equal engine (R).
+    Returns (final_values, threads_used)."""
+    global _asref
+    if _asref is None:
+        so = os.path.join(_HERE, "libsmmc_asref.so")
+        src = os.path.join(_HERE, "asref_cpu.cpp")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "libsmmc_asref.so"], stdout=subprocess.DEVNULL)
+        L = C.CDLL(so)
+        L.orc_asref_mc_simulations.restype = C.c_int
+        L.orc_asref_mc_simulations.argtypes = [C.c_int64, C.c_uint32, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p,
+                                               C.c_int, C.c_int, C.c_uint32]
+        _asref = L
+    t = _f32(table)
+    out = np.empty(n_paths, dtype=np.float32)
+    used = _asref.orc_asref_mc_simulations(n_paths, n_periods, float(initial_capital), t.ctypes.data_as(C.c_void_p),
+                                           t.size, out.ctypes.data_as(C.c_void_p), n_threads,
+                                           0 if fixed_seed0 is None else 1,
+                                           C.c_uint32((fixed_seed0 or 0) & 0xFFFFFFFF))
+    return out, used
+
+
 def make_params(mode, n_periods, n_paths, seed, first_path=0, initial_capital=1000.0, table=None,
                 gauss_mean=0.5, gauss_std=0.83333, n_bins=0, hist_lo=0.0, hist_hi=1.0,
                 below_threshold=1000.0):
