@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SMMC_ABI_VERSION 1
+#define SMMC_ABI_VERSION 2
 
 /* return codes */
 #define SMMC_OK 0
@@ -122,6 +122,13 @@ int smmc_device_count(int *count);
 int smmc_engine_create(int device, void *stream, smmc_engine **out);
 void smmc_engine_destroy(smmc_engine *e);
 
+/* Re-binds the engine to another stream of its device (e.g. the caller's CURRENT torch stream,
+ * passed before every call).  Work already enqueued stays ordered before anything enqueued
+ * afterwards.  An engine-owned stream is drained and destroyed.  smmc_engine_get_stream returns the
+ * handle launches go to (so a caller can order its own streams against an engine-owned one). */
+int smmc_engine_set_stream(smmc_engine *e, void *stream);
+int smmc_engine_get_stream(smmc_engine *e, void **stream);
+
 /* Uploads the historical-returns table (percent units, host memory).  Replaces
  * the H2D table copies at src/simulations.cu:382,451,525,617.  Waits for work already
  * enqueued on the engine stream; the host array may be reused on return. */
@@ -150,6 +157,14 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
 /* Blocks until everything enqueued on the engine stream has finished. */
 int smmc_engine_sync(smmc_engine *e);
 
+/* Progress callback of the synchronous *_to_host entry points: called on the calling thread
+ * with the number of paths whose results are in the caller's memory -- 0 at the start, after every
+ * finished chunk, n_paths at the end.  The C++ drop-in layer stores it into the caller's
+ * std::atomic<long> n_simulations (src/simulations.cpp:254; polled by
+ * examples/visualize_returns_cpu_v2.cpp:360-376).  NULL clears it. */
+typedef void (*smmc_progress_fn)(void *user, int64_t finished_paths);
+int smmc_engine_set_progress(smmc_engine *e, smmc_progress_fn fn, void *user);
+
 /* Simulates into HOST memory: outputs are produced in chunks of 2^24 paths and
  * copied back on a side stream while the next chunk computes (the async
  * cudaMemcpy pattern of mc_simulations_multi_gpu_launcher_async,
@@ -158,8 +173,14 @@ int smmc_engine_sync(smmc_engine *e);
  *   host_final       n_paths floats
  *   host_chunk_mean  ceil(n_paths / SMMC_CHUNK) floats  (means of the reduceBlock API)
  *   host_chunk_var   same length                         (variances)
- *   progress         set to the number of finished paths after every chunk (the
- *                    n_simulations counter of src/simulations.cpp:254)
+ *   progress         set (atomic release store) to the number of finished paths after every
+ *                    chunk (the n_simulations counter of src/simulations.cpp:254); when it or a
+ *                    progress callback is given, chunks shrink to about n_paths / 16 (at least
+ *                    2^20 paths) so that a poller sees the run advance
+ * Environment: SMMC_PIN_HOST=whole|chunk page-locks host_final (hipHostRegister) for the call when
+ * it is not pinned already -- whole buffer up front, or chunk by chunk one chunk ahead of the
+ * copies; default off (registration costs more than it saves on a single run);
+ * SMMC_HOST_CHUNK_PATHS overrides the chunk length.  Results never depend on either.
  *   stats, hist      merged statistics header and n_bins bucket counts
  * Synchronous. */
 int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *host_final,

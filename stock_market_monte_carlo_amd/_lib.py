@@ -9,7 +9,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsmmc_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MODE_TABLE = 0
 MODE_GAUSSIAN = 1
 FLAG_EXACT_DIV = 1
@@ -66,6 +66,9 @@ SYMBOLS = [
     ("smmc_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("smmc_engine_create", C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     ("smmc_engine_destroy", None, [C.c_void_p]),
+    ("smmc_engine_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("smmc_engine_get_stream", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("smmc_engine_set_progress", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("smmc_engine_set_table", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     ("smmc_engine_simulate", C.c_int,
      [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -59,7 +59,8 @@ struct DeviceGuard {
 // are handed out as others finish, which evens out CU/XCD speed differences: measured
 // 1e8 x 360 table paths: 13.1 ms at 6 per CU, 12.6 at 8, 11.7 at 16, 11.1 at 64..256.
 constexpr uint32_t kBlocksPerCU = 64;
-constexpr uint64_t kHostChunkPaths = 1ull << 24;  // simulate_to_host: 64 MiB of floats per chunk
+constexpr uint64_t kHostChunkPaths = 1ull << 24;     // simulate_to_host: 64 MiB of floats per chunk
+constexpr uint64_t kProgressChunkMin = 1ull << 20;   // ... and at least this many when progress is polled
 
 }  // namespace
 
@@ -100,6 +101,12 @@ struct smmc_engine {
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;  // pairs: start, stop
   size_t ev_used = 0;
+
+  uint64_t host_chunk_paths = kHostChunkPaths;  // SMMC_HOST_CHUNK_PATHS
+  int pin_policy = 0;                           // SMMC_PIN_HOST: 0 never, 1 whole buffer, 2 chunk by chunk
+  uint64_t pin_min_bytes = 32ull << 20;
+  smmc_progress_fn progress_fn = nullptr;
+  void *progress_user = nullptr;
 };
 
 namespace {
@@ -310,6 +317,15 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     const long v = std::strtol(env, nullptr, 10);
     if (v >= 1 && v <= 4096) e->keepdata_blocks_per_cu = static_cast<uint32_t>(v);
   }
+  if (const char *env = std::getenv("SMMC_HOST_CHUNK_PATHS")) {  // tuning/test knob, results do not depend on it
+    const long long v = std::strtoll(env, nullptr, 10);
+    if (v >= smmc::kBlock) e->host_chunk_paths = static_cast<uint64_t>(v) / smmc::kBlock * smmc::kBlock;
+  }
+  if (const char *env = std::getenv("SMMC_PIN_HOST")) {  // see smmc_engine_simulate_to_host
+    if (!std::strcmp(env, "1") || !std::strcmp(env, "whole")) e->pin_policy = 1;
+    else if (!std::strcmp(env, "chunk")) e->pin_policy = 2;
+    else e->pin_policy = 0;
+  }
   // dynamic LDS a launch may ask for: the kernels opt in above the 64 KiB default (CDNA4: 160 KiB per CU)
   e->max_lds = std::max<size_t>(prop.sharedMemPerBlock, 128u * 1024u);
   if (stream != SMMC_STREAM_NEW) {
@@ -475,6 +491,42 @@ int smmc_engine_sync(smmc_engine *e) {
   return SMMC_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Page-locks [p, p + bytes) for the lifetime of the object unless the range already is (a
+// hipHostMalloc'd or registered buffer), so that D2H copies into it run at the pinned rate without
+// the runtime's staging.  Failure is not an error: the copy then takes the pageable path.
+struct HostPin {
+  void *p = nullptr;
+  hipStream_t drain = nullptr;  // stream whose copies may still target the range when an error unwinds
+  bool pin(void *ptr, size_t bytes) {
+    release();
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) == hipSuccess && attr.type != hipMemoryTypeUnregistered) return true;
+    (void)hipGetLastError();
+    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    p = ptr;
+    return true;
+  }
+  void release() {
+    if (p) (void)hipHostUnregister(p);
+    p = nullptr;
+  }
+  ~HostPin() {
+    if (p && drain) (void)hipStreamSynchronize(drain);
+    release();
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
 int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *host_final,
                                  float *host_chunk_mean, float *host_chunk_var, volatile int64_t *progress,
                                  smmc_stats *stats, uint64_t *hist) {
@@ -483,7 +535,16 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
   const uint64_t n = sim->n_paths;
-  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), kHostChunkPaths);  // multiple of 256 when n > chunk
+  const bool polled = progress != nullptr || e->progress_fn != nullptr;
+  // chunk: a multiple of 256 paths.  64 MiB of floats by default; when a caller polls the progress
+  // counter (the reference advances it every 1000 paths, src/simulations.cpp:254, and its GUIs redraw
+  // from it, examples/visualize_returns_cpu_v2.cpp:360-376) about 16 steps per run, at least 2^20 paths
+  uint64_t chunk_max = e->host_chunk_paths;
+  if (polled && e->host_chunk_paths == kHostChunkPaths) {
+    const uint64_t sixteenth = (n / 16 + smmc::kBlock - 1) / smmc::kBlock * smmc::kBlock;
+    chunk_max = std::min<uint64_t>(kHostChunkPaths, std::max<uint64_t>(kProgressChunkMin, sixteenth));
+  }
+  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), chunk_max);
   const uint64_t n_chunks = (n + chunk - 1) / chunk;
   const bool want_stats = stats != nullptr || hist != nullptr;
   const bool want_cs = host_chunk_mean != nullptr || host_chunk_var != nullptr;
@@ -521,7 +582,22 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
     SMMC_HIP(hipMalloc(&e->d_stage_stats, rec * std::max<uint64_t>(n_chunks, 1)));
     e->stage_stats_bytes = rec * std::max<uint64_t>(n_chunks, 1);
   }
-  if (progress) *progress = 0;
+  auto report = [&](uint64_t done) {
+    if (progress) __atomic_store_n(const_cast<int64_t *>(progress), static_cast<int64_t>(done), __ATOMIC_RELEASE);
+    if (e->progress_fn) e->progress_fn(e->progress_user, static_cast<int64_t>(done));
+  };
+  report(0);
+
+  // Pinning the caller's result buffer (SMMC_PIN_HOST, default off: see DESIGN.md section 6 for the
+  // measurements).  "whole": one hipHostRegister over all of host_final before the first chunk;
+  // "chunk": chunk c + 1 is registered by this host thread while chunk c computes, and chunk c is
+  // released once its copy has finished.  Buffers that are pinned already are left alone.
+  HostPin pin_all, pin_chunk[2];
+  pin_all.drain = pin_chunk[0].drain = pin_chunk[1].drain = e->copy_stream;
+  const bool pin_whole = host_final && e->pin_policy == 1 && sizeof(float) * n >= e->pin_min_bytes;
+  const bool pin_chunks = host_final && e->pin_policy == 2 && sizeof(float) * n >= e->pin_min_bytes;
+  if (pin_whole) (void)pin_all.pin(host_final, sizeof(float) * n);
+  if (pin_chunks) (void)pin_chunk[0].pin(host_final, sizeof(float) * std::min<uint64_t>(chunk, n));
 
   // Pipeline: the kernel of chunk c (engine stream) overlaps the D2H copies of chunk
   // c - 1 (copy stream).  Buffer b = c & 1 is reused once its copies have finished.
@@ -551,15 +627,30 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
         SMMC_HIP(hipMemcpyAsync(host_chunk_var + c * cs_per_chunk, d_cv, sizeof(float) * cs_here,
                                 hipMemcpyDeviceToHost, e->copy_stream));
       SMMC_HIP(hipEventRecord(e->ev_copy[b], e->copy_stream));
-      if (progress && c >= 1) {
-        SMMC_HIP(hipEventSynchronize(e->ev_copy[b ^ 1]));
-        *progress = static_cast<int64_t>(c * chunk);
+      if ((polled || pin_chunks) && c >= 1) {
+        SMMC_HIP(hipEventSynchronize(e->ev_copy[b ^ 1]));  // chunks 0 .. c - 1 are in the caller's memory
+        report(c * chunk);
+      }
+      if (pin_chunks) {  // chunk c - 1 is home: release it, pin chunk c + 1 while chunk c computes
+        pin_chunk[b ^ 1].release();
+        if (c + 1 < n_chunks)
+          (void)pin_chunk[b ^ 1].pin(host_final + (c + 1) * chunk,
+                                     sizeof(float) * std::min<uint64_t>(chunk, n - (c + 1) * chunk));
+      }
+    } else if (polled) {
+      // nothing is copied per chunk: chunks 0 .. c - 1 are finished when the kernel of c - 1 is
+      SMMC_HIP(hipEventRecord(e->ev_compute[b], e->stream));
+      if (c >= 1) {
+        SMMC_HIP(hipEventSynchronize(e->ev_compute[b ^ 1]));
+        report(c * chunk);
       }
     }
   }
   SMMC_HIP(hipStreamSynchronize(e->stream));
   if (copies) SMMC_HIP(hipStreamSynchronize(e->copy_stream));
-  if (progress) *progress = static_cast<int64_t>(n);
+  pin_chunk[0].release();
+  pin_chunk[1].release();
+  pin_all.release();
 
   if (want_stats) {
     std::vector<char> all(rec * std::max<uint64_t>(n_chunks, 1));
@@ -578,6 +669,7 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
     if (stats) *stats = *h;
     if (hist && sim->n_bins) std::memcpy(hist, acc.data() + sizeof(smmc_stats), sizeof(uint64_t) * sim->n_bins);
   }
+  report(n);
   return SMMC_OK;
 }
 
@@ -784,6 +876,40 @@ int smmc_engine_host_values_summary(smmc_engine *e, const float *host_values, ui
   (void)hipFree(d);
   if (rc) return rc;
   if (err != hipSuccess) return fail(SMMC_ERR_HIP, "host_values_summary failed: %s", hipGetErrorString(err));
+  return SMMC_OK;
+}
+
+int smmc_engine_set_stream(smmc_engine *e, void *stream) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  if (stream == SMMC_STREAM_NEW) return fail(SMMC_ERR_INVALID, "smmc_engine_set_stream takes a stream handle");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (s == e->stream) return SMMC_OK;
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  // work already enqueued keeps its order: the new stream waits for the old one's tail (the
+  // engine's workspace -- partials, staging -- is shared between consecutive launches)
+  if (!e->ev_compute[0]) SMMC_HIP(hipEventCreateWithFlags(&e->ev_compute[0], hipEventDisableTiming));
+  SMMC_HIP(hipEventRecord(e->ev_compute[0], e->stream));
+  SMMC_HIP(hipStreamWaitEvent(s, e->ev_compute[0], 0));
+  if (e->own_stream) {
+    SMMC_HIP(hipStreamSynchronize(e->stream));
+    SMMC_HIP(hipStreamDestroy(e->stream));
+    e->own_stream = false;
+  }
+  e->stream = s;
+  return SMMC_OK;
+}
+
+int smmc_engine_get_stream(smmc_engine *e, void **stream) {
+  if (!e || !stream) return fail(SMMC_ERR_INVALID, "NULL argument");
+  *stream = static_cast<void *>(e->stream);
+  return SMMC_OK;
+}
+
+int smmc_engine_set_progress(smmc_engine *e, smmc_progress_fn fn, void *user) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  e->progress_fn = fn;
+  e->progress_user = fn ? user : nullptr;
   return SMMC_OK;
 }
 

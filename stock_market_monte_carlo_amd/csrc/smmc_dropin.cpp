@@ -6,6 +6,7 @@
 // everything device-side goes through smmc.h.
 #include "stock_market_monte_carlo/simulations.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,13 +19,11 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <utility>
 
 #include "smmc.h"
 
 namespace {
-
-static_assert(sizeof(std::atomic<long>) == sizeof(int64_t) && std::atomic<long>::is_always_lock_free,
-              "the progress counter is updated through a plain 64-bit store");
 
 [[noreturn]] void raise(int rc) {
   std::string msg = std::string("smmc: ") + smmc_last_error();
@@ -45,11 +44,11 @@ struct Slot {
   }
 };
 std::mutex g_slots_mutex;
-std::map<int, std::unique_ptr<Slot>> g_slots;
+std::map<std::pair<int, int>, std::unique_ptr<Slot>> g_slots;  // (device, lane): lane > 0 only under SMMC_DEVICE_MAP
 
-Slot &slot_for(int device) {
+Slot &slot_for(int device, int lane = 0) {
   std::lock_guard<std::mutex> lock(g_slots_mutex);
-  auto &s = g_slots[device];
+  auto &s = g_slots[{device, lane}];
   if (!s) s.reset(new Slot());
   return *s;
 }
@@ -89,15 +88,47 @@ int visible_devices() {
   return n;
 }
 
-// Runs `work(device, first_path, count)` for each of n_gpus contiguous shards, one host
-// thread per device.  Shard g covers floor(N/G) paths plus one of the N mod G leftovers
+// SMMC_DEVICE_MAP="0,0,1": shard g of an n_gpus-way call runs on device map[g] (several shards may
+// share a device; each then has its own engine and stream).  Without it shard g runs on device g, as
+// the reference's cudaSetDevice(k) loop does (src/simulations.cu:599-626).  Lets the multi-shard code
+// path -- thread fan-out, per-shard engines, host merge -- run on a box with fewer GPUs than n_gpus.
+std::vector<int> device_map(int n_gpus) {
+  std::vector<int> map;
+  if (const char *env = std::getenv("SMMC_DEVICE_MAP")) {
+    std::stringstream ss(env);
+    std::string cell;
+    while (std::getline(ss, cell, ',')) {
+      char *end = nullptr;
+      const long v = std::strtol(cell.c_str(), &end, 10);
+      if (end == cell.c_str() || v < 0) throw std::invalid_argument("smmc: SMMC_DEVICE_MAP must be a comma-separated list of device ids");
+      map.push_back(static_cast<int>(v));
+    }
+    if (static_cast<int>(map.size()) < n_gpus)
+      throw std::invalid_argument("smmc: SMMC_DEVICE_MAP names fewer devices than n_gpus");
+    map.resize(n_gpus);
+    return map;
+  }
+  for (int g = 0; g < n_gpus; ++g) map.push_back(g);
+  return map;
+}
+
+struct Shard {
+  int index;   // 0 .. n_gpus - 1: results merge in this order
+  int device;  // where it runs
+  int lane;    // how many earlier shards share that device (0 without SMMC_DEVICE_MAP): picks the engine
+  std::uint64_t first, count;
+};
+
+// Runs `work(shard)` for each of n_gpus contiguous shards, one host thread per shard.  Shard g covers floor(N/G) paths plus one of the N mod G leftovers
 // (the reference drops the remainder, src/simulations.cu:602-603).
 template <typename Work>
 void for_each_shard(long n_total, int n_gpus, Work work) {
   if (n_gpus < 1) throw std::invalid_argument("smmc: n_gpus must be >= 1");
   const int have = visible_devices();
   if (have == 0) throw std::runtime_error("smmc: no MI355X visible; this library has no CPU fallback");
-  if (n_gpus > have) throw std::invalid_argument("smmc: n_gpus exceeds the visible devices");
+  const std::vector<int> map = device_map(n_gpus);
+  for (int d : map)
+    if (d >= have) throw std::invalid_argument("smmc: n_gpus exceeds the visible devices");
   const std::uint64_t n = static_cast<std::uint64_t>(n_total);
   const std::uint64_t base = n / n_gpus, extra = n % n_gpus;
   std::vector<std::thread> threads;
@@ -105,9 +136,12 @@ void for_each_shard(long n_total, int n_gpus, Work work) {
   std::uint64_t first = 0;
   for (int g = 0; g < n_gpus; ++g) {
     const std::uint64_t count = base + (static_cast<std::uint64_t>(g) < extra ? 1 : 0);
-    auto body = [&, g, first, count]() {
+    int lane = 0;
+    for (int h = 0; h < g; ++h) lane += map[h] == map[g];
+    const Shard shard{g, map[g], lane, first, count};
+    auto body = [&, g, shard]() {
       try {
-        work(g, first, count);
+        work(shard);
       } catch (const std::exception &ex) {
         errors[g] = ex.what();
       }
@@ -124,8 +158,8 @@ void for_each_shard(long n_total, int n_gpus, Work work) {
 struct Session {
   std::unique_lock<std::mutex> lock;
   smmc_engine *engine;
-  Session(int device, const std::vector<float> *table) : lock(slot_for(device).busy) {
-    Slot &s = slot_for(device);
+  Session(int device, const std::vector<float> *table, int lane = 0) : lock(slot_for(device, lane).busy) {
+    Slot &s = slot_for(device, lane);
     if (!s.engine) check(smmc_engine_create(device, SMMC_STREAM_NEW, &s.engine));
     engine = s.engine;
     if (table) {
@@ -135,28 +169,54 @@ struct Session {
   }
 };
 
+// Progress of a run that may be split over several shards: every engine reports its own finished-path
+// count through smmc_engine_set_progress; the deltas are added to the caller's atomic counter.
+struct Progress {
+  std::atomic<long> *counter;
+  long reported = 0;
+  static void on_progress(void *user, int64_t finished) {
+    Progress *p = static_cast<Progress *>(user);
+    const long now = static_cast<long>(finished);
+    if (now > p->reported) {
+      p->counter->fetch_add(now - p->reported, std::memory_order_release);
+      p->reported = now;
+    }
+  }
+};
+
+double seconds_since(const std::chrono::steady_clock::time_point &t0) {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+bool verbose() {
+  const char *env = std::getenv("SMMC_VERBOSE");
+  return env && *env && *env != '0';
+}
+
 void run_final_values(std::atomic<long> &n_simulations, long n_total, unsigned periods, float capital, int mode,
                       const std::vector<float> *table, float mean, float stddev, float *out, int n_gpus) {
   const std::uint64_t seed = next_seed();
   n_simulations = 0;
-  if (n_gpus == 1) {
-    Session ses(0, table);
-    smmc_sim sim = make_sim(mode, seed, 0, static_cast<std::uint64_t>(n_total), periods, capital);
+  const auto t_all = std::chrono::steady_clock::now();
+  for_each_shard(n_total, n_gpus, [&](const Shard &sh) {
+    const std::uint64_t first = sh.first, count = sh.count;
+    const int shard = sh.index, dev = sh.device;
+    const auto t0 = std::chrono::steady_clock::now();
+    Session ses(dev, table, sh.lane);
+    const double t_session = seconds_since(t0);
+    smmc_sim sim = make_sim(mode, seed, first, count, periods, capital);
     sim.gauss_mean = mean;
     sim.gauss_std = stddev;
-    // the engine stores finished-path counts straight into the caller's counter
-    check(smmc_engine_simulate_to_host(ses.engine, &sim, out, nullptr, nullptr,
-                                       reinterpret_cast<volatile int64_t *>(&n_simulations), nullptr, nullptr));
-  } else {
-    for_each_shard(n_total, n_gpus, [&](int dev, std::uint64_t first, std::uint64_t count) {
-      Session ses(dev, table);
-      smmc_sim sim = make_sim(mode, seed, first, count, periods, capital);
-      sim.gauss_mean = mean;
-      sim.gauss_std = stddev;
-      check(smmc_engine_simulate_to_host(ses.engine, &sim, out + first, nullptr, nullptr, nullptr, nullptr, nullptr));
-      n_simulations += static_cast<long>(count);
-    });
-  }
+    Progress prog{&n_simulations};
+    check(smmc_engine_set_progress(ses.engine, &Progress::on_progress, &prog));
+    const int rc = smmc_engine_simulate_to_host(ses.engine, &sim, out + first, nullptr, nullptr, nullptr, nullptr, nullptr);
+    (void)smmc_engine_set_progress(ses.engine, nullptr, nullptr);
+    check(rc);
+    if (verbose())  // phase timers, as the reference's launchers print them (src/simulations.cu:351-358,608-610)
+      std::fprintf(stderr, "smmc: shard %d on device %d: paths [%llu, %llu): engine+table %.3f s, simulate+copy %.3f s\n",
+                   shard, dev, (unsigned long long)first, (unsigned long long)(first + count), t_session,
+                   seconds_since(t0) - t_session);
+  });
+  if (verbose()) std::fprintf(stderr, "smmc: %ld paths x %u periods on %d shard(s): %.3f s\n", n_total, periods, n_gpus, seconds_since(t_all));
   n_simulations = n_total;  // src/simulations.cu:678
 }
 
@@ -357,8 +417,12 @@ void update_quartiles(std::vector<float> &quartiles, std::vector<float> &vec, lo
 void update_mean_std(float &mean, float &std, std::vector<float> &v, long n_el) {
   smmc_stats st;
   summary_of(v, n_el, 0.f, &st, nullptr);
-  mean = static_cast<float>(st.sum / static_cast<double>(n_el));  // examples/visualize_returns_cpu_v2.cpp:117-122
-  std = static_cast<float>(std::sqrt(st.sumsq / static_cast<double>(n_el) - static_cast<double>(mean) * mean));
+  // examples/visualize_returns_cpu_v2.cpp:113-123 sums (v - mean)^2, which cannot go negative; from
+  // one pass the variance is formed with the DOUBLE mean and clamped, and only then rounded (with the
+  // float-rounded mean the error 2 * mean * ulp(mean) swamps a small variance: 1000.013 +- 0.05 gave 0.18)
+  const double m = st.sum / static_cast<double>(n_el);
+  mean = static_cast<float>(m);
+  std = static_cast<float>(std::sqrt(std::max(st.sumsq / static_cast<double>(n_el) - m * m, 0.0)));
 }
 
 long update_count_below_min(float &min_final_amount, const std::vector<float> &final_values, long n_simulations) {
@@ -395,8 +459,10 @@ Summary mc_summary(long max_n_simulations, int n_periods, float initial_capital,
   const std::uint64_t seed = next_seed();
   const size_t rec = static_cast<size_t>(smmc_stats_bytes(n_bins));
   std::vector<std::vector<char>> records(n_gpus > 0 ? n_gpus : 1, std::vector<char>(rec));
-  for_each_shard(max_n_simulations, n_gpus, [&](int dev, std::uint64_t first, std::uint64_t count) {
-    Session ses(dev, gaussian ? nullptr : &returns);
+  for_each_shard(max_n_simulations, n_gpus, [&](const Shard &sh) {
+    const std::uint64_t first = sh.first, count = sh.count;
+    const int shard = sh.index;
+    Session ses(sh.device, gaussian ? nullptr : &returns, sh.lane);
     smmc_sim sim = make_sim(gaussian ? SMMC_MODE_GAUSSIAN : SMMC_MODE_TABLE, seed, first, count,
                             static_cast<unsigned>(n_periods), initial_capital);
     sim.gauss_mean = return_mean;
@@ -405,12 +471,12 @@ Summary mc_summary(long max_n_simulations, int n_periods, float initial_capital,
     sim.n_bins = n_bins;
     sim.hist_lo = hist_lo;
     sim.hist_hi = hist_hi;
-    smmc_stats *hdr = reinterpret_cast<smmc_stats *>(records[dev].data());
+    smmc_stats *hdr = reinterpret_cast<smmc_stats *>(records[shard].data());
     check(smmc_engine_simulate_to_host(ses.engine, &sim, nullptr, nullptr, nullptr, nullptr, hdr,
-                                       reinterpret_cast<uint64_t *>(records[dev].data() + sizeof(smmc_stats))));
+                                       reinterpret_cast<uint64_t *>(records[shard].data() + sizeof(smmc_stats))));
     hdr->n_bins = n_bins;
   });
-  for (int g = 1; g < n_gpus; ++g) check(smmc_stats_merge(records[0].data(), records[g].data()));  // device order
+  for (int g = 1; g < n_gpus; ++g) check(smmc_stats_merge(records[0].data(), records[g].data()));  // shard order
   const smmc_stats *h = reinterpret_cast<const smmc_stats *>(records[0].data());
   Summary out;
   out.count = h->count;

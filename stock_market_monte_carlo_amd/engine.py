@@ -91,10 +91,38 @@ class Engine:
         else:
             sp = int(stream)
         self.own_stream = sp == -1
+        self.follow_torch = stream == "torch"
         h = C.c_void_p()
         _lib.check(self._L.smmc_engine_create(self.device, C.c_void_p(sp), C.byref(h)))
         self._h = h
         self.table_len = 0
+        self._ext = None
+        if self.own_stream:
+            # torch's view of the engine-owned stream: lets torch-allocated outputs be ordered against it
+            raw = C.c_void_p()
+            _lib.check(self._L.smmc_engine_get_stream(self._h, C.byref(raw)))
+            self._ext = torch.cuda.ExternalStream(raw.value, device=self.tdevice)
+
+    # -- stream discipline ---------------------------------------------------
+    def _enter(self):
+        """Before enqueuing: launches go to the caller's CURRENT torch stream (a "torch" engine
+        re-binds on every call: the caller may be inside `with torch.cuda.stream(s)` now), or the
+        engine's own stream first waits for it (its outputs were just allocated there)."""
+        cur = self._torch.cuda.current_stream(self.tdevice)
+        if self.follow_torch:
+            _lib.check(self._L.smmc_engine_set_stream(self._h, C.c_void_p(int(cur.cuda_stream))))
+        elif self._ext is not None:
+            self._ext.wait_stream(cur)
+        return cur
+
+    def _leave(self, cur, *tensors):
+        """After enqueuing on an engine-owned stream: torch's current stream waits for the results,
+        and the caching allocator learns that the engine stream uses these blocks."""
+        if self._ext is not None:
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self._ext)
+            cur.wait_stream(self._ext)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -174,14 +202,22 @@ class Engine:
             res.stats_raw = torch.empty(int(self._L.smmc_stats_bytes(sim.n_bins)), dtype=torch.uint8,
                                         device=self.tdevice)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None  # noqa: E731
+        cur = self._enter()
         _lib.check(self._L.smmc_engine_simulate(self._h, C.byref(sim), ptr(res.final), ptr(res.chunk_mean),
                                                 ptr(res.chunk_var), ptr(res.stats_raw)))
+        self._leave(cur, res.final, res.chunk_mean, res.chunk_var, res.stats_raw)
         return res
 
     def read_stats(self, stats_raw):
         """Copies a device record to the host after the engine stream has drained."""
         self.sync()
         return stats_from_bytes(stats_raw.cpu().numpy().tobytes())
+
+    def stream_handle(self):
+        """The hipStream_t (as an int) launches currently go to."""
+        raw = C.c_void_p()
+        _lib.check(self._L.smmc_engine_get_stream(self._h, C.byref(raw)))
+        return int(raw.value or 0)
 
     # -- statistics of values already in HBM (SURVEY section 8f) ---------------------
     def _check_values(self, values):
@@ -193,9 +229,11 @@ class Engine:
         """One HBM pass over a device tensor -> packed statistics record (device uint8 tensor)."""
         self._check_values(values)
         rec = self._torch.empty(int(self._L.smmc_stats_bytes(n_bins)), dtype=self._torch.uint8, device=self.tdevice)
+        cur = self._enter()
         _lib.check(self._L.smmc_engine_values_stats(self._h, C.c_void_p(values.data_ptr()), values.numel(),
                                                     below_threshold, n_bins, hist_lo, hist_hi,
                                                     C.c_void_p(rec.data_ptr())))
+        self._leave(cur, rec, values)
         return rec
 
     def order_statistics(self, values, ranks):
@@ -203,6 +241,7 @@ class Engine:
         self._check_values(values)
         r = np.ascontiguousarray(ranks, dtype=np.uint64)
         out = np.empty(r.size, dtype=np.float32)
+        self._leave(self._enter(), values)  # synchronous call: only the input needs ordering
         _lib.check(self._L.smmc_engine_order_statistics(self._h, C.c_void_p(values.data_ptr()), values.numel(),
                                                         r.ctypes.data_as(C.c_void_p), r.size,
                                                         out.ctypes.data_as(C.c_void_p)))
@@ -212,6 +251,7 @@ class Engine:
         """{min, Q1, Q2, Q3, max}: update_quartiles, examples/visualize_returns_cpu_v2.cpp:83-111."""
         self._check_values(values)
         out = np.empty(5, dtype=np.float32)
+        self._leave(self._enter(), values)
         _lib.check(self._L.smmc_engine_quartiles(self._h, C.c_void_p(values.data_ptr()), values.numel(),
                                                  out.ctypes.data_as(C.c_void_p)))
         return out
@@ -237,9 +277,11 @@ class Engine:
         traj = torch.empty((n, p + 1), dtype=torch.float32, device=self.tdevice)
         final = torch.empty(n, dtype=torch.float32, device=self.tdevice) if want_final else None
         if n:
+            cur = self._enter()
             _lib.check(self._L.smmc_engine_simulate_keepdata(
                 self._h, C.byref(sim), C.c_void_p(traj.data_ptr()),
                 C.c_void_p(final.data_ptr()) if final is not None else None))
+            self._leave(cur, traj, final)
         return traj, final
 
     def simulate_to_host(self, sim, out=None, want_stats=False, want_chunk_stats=False, progress=None):
@@ -253,10 +295,10 @@ class Engine:
         nc = (n + _lib.CHUNK - 1) // _lib.CHUNK
         cm = np.empty(nc, dtype=np.float32) if want_chunk_stats else None
         cv = np.empty(nc, dtype=np.float32) if want_chunk_stats else None
-        prog = progress if progress is not None else C.c_int64(0)
         vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+        self._enter()  # synchronous: returns with both of its streams drained
         _lib.check(self._L.smmc_engine_simulate_to_host(
-            self._h, C.byref(sim), vp(host), vp(cm), vp(cv), C.byref(prog),
+            self._h, C.byref(sim), vp(host), vp(cm), vp(cv), C.byref(progress) if progress is not None else None,
             C.byref(st) if want_stats else None, vp(hist) if want_stats else None))
         stats = None
         if want_stats:
@@ -268,6 +310,7 @@ class Engine:
         n, p = int(sim.n_paths), int(sim.n_periods)
         traj = np.empty((n, p + 1), dtype=np.float32)
         final = np.empty(n, dtype=np.float32)
+        self._enter()
         _lib.check(self._L.smmc_engine_simulate_keepdata_to_host(
             self._h, C.byref(sim), traj.ctypes.data_as(C.c_void_p), final.ctypes.data_as(C.c_void_p)))
         return traj, final
@@ -280,11 +323,27 @@ class Engine:
 _engines = {}
 
 
-def _engine(device=0):
-    e = _engines.get(device)
+def _engine(device=0, lane=0):
+    """One engine per (device, lane); lane > 0 only when SMMC_DEVICE_MAP puts several shards of one
+    call on the same device."""
+    e = _engines.get((device, lane))
     if e is None:
-        e = _engines[device] = Engine(device)
+        e = _engines[(device, lane)] = Engine(device)
     return e
+
+
+def _device_map(n_gpus):
+    """Shard g of an n_gpus-way call runs on device map[g]: g itself, or SMMC_DEVICE_MAP="0,0,1"
+    (the same hook as the C++ layer's, csrc/smmc_dropin.cpp)."""
+    import torch
+    env = os.environ.get("SMMC_DEVICE_MAP")
+    devs = [int(x) for x in env.split(",")][:n_gpus] if env else list(range(n_gpus))
+    if len(devs) < n_gpus:
+        raise ValueError("SMMC_DEVICE_MAP names fewer devices than n_gpus")
+    have = torch.cuda.device_count()
+    if n_gpus < 1 or any(d < 0 or d >= have for d in devs):
+        raise ValueError(f"n_gpus={n_gpus} but {have} device(s) visible")
+    return devs
 
 
 def _seed(seed):
@@ -326,22 +385,39 @@ def read_historical_returns(csv_fpath):
 
 def mc_simulations_gpu(max_n_simulations, n_periods, initial_capital, returns, n_gpus=1, seed=None):
     """simulations.h:73-79, src/simulations.cu:661-680: final value of every path (host array).
-    Paths shard over n_gpus devices of this process by contiguous global id ranges."""
-    import torch
-    if n_gpus < 1 or n_gpus > torch.cuda.device_count():
-        raise ValueError(f"n_gpus={n_gpus} but {torch.cuda.device_count()} device(s) visible")
+    Paths shard over n_gpus devices of this process by contiguous global id ranges, one host thread
+    per shard so that all devices compute and copy at once (the reference's async launcher,
+    src/simulations.cu:599-626; ctypes releases the GIL for the duration of the call)."""
+    import threading
+    from .dist import shard_range
+    devs = _device_map(n_gpus)
     seed = _seed(seed)
     n = int(max_n_simulations)
     out = np.empty(n, dtype=np.float32)
-    base, extra = divmod(n, n_gpus)
-    first = 0
-    for g in range(n_gpus):
-        cnt = base + (1 if g < extra else 0)
-        e = _engine(g)
-        e.set_table(returns)
-        sim = Engine.make_sim(cnt, n_periods, MODE_TABLE, seed, first_path=first, initial_capital=initial_capital)
-        e.simulate_to_host(sim, out=out[first:first + cnt])
-        first += cnt
+    errors = []
+
+    def run(g):
+        try:
+            first, cnt = shard_range(n, n_gpus, g)
+            import torch
+            with torch.cuda.device(devs[g]):
+                e = _engine(devs[g], devs[:g].count(devs[g]))
+                e.set_table(returns)
+                sim = Engine.make_sim(cnt, n_periods, MODE_TABLE, seed, first_path=first, initial_capital=initial_capital)
+                e.simulate_to_host(sim, out=out[first:first + cnt])
+        except Exception as ex:  # re-raised on the calling thread
+            errors.append(ex)
+
+    if n_gpus == 1:
+        run(0)
+    else:
+        threads = [threading.Thread(target=run, args=(g,)) for g in range(n_gpus)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
     return out
 
 
@@ -402,8 +478,10 @@ def update_mean_std(v, n_el):
     """examples/visualize_returns_cpu_v2.cpp:113-123: (mean, population std) as floats."""
     e = _engine(0)
     st = e.read_stats(e.values_stats(_to_device(v, n_el)))
-    mean = np.float32(st.sum / n_el)
-    return float(mean), float(np.float32(np.sqrt(st.sumsq / n_el - float(mean) * float(mean))))
+    # variance from the DOUBLE mean, clamped, then rounded: with the float-rounded mean the error
+    # 2 * mean * ulp(mean) swamps a small variance (the reference sums (v - mean)^2 instead)
+    m = st.sum / n_el
+    return float(np.float32(m)), float(np.float32(np.sqrt(max(st.sumsq / n_el - m * m, 0.0))))
 
 
 def update_count_below_min(min_final_amount, final_values, n_simulations):

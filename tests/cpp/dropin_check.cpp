@@ -1,7 +1,10 @@
 // dropin_check.cpp -- exercises the reference-named C++ API (simulations.h) the way the
 // reference's callers do and prints one JSON object for tests/test_dropin_gpu.py.
 #include <cinttypes>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <set>
 #include <cstring>
 #include <stdexcept>
 #include <thread>
@@ -97,7 +100,70 @@ int main(int argc, char **argv) {
   const bool concurrent_ok = fnv(conc_final) == fnv(cpu_final) && fnv(conc_keep_final) == fnv(keep_final) &&
                              conc_data[nk - 1] == mc_data[nk - 1];
 
+  // n_gpus > 1 (SMMC_DEVICE_MAP lets three shards share this box's one GPU): the path ids are global,
+  // so the result must not depend on the split; the N mod 3 remainder is kept (src/simulations.cu:602-603 drops it)
+  bool multi_ran = false, multi_same = false, multi_summary_same = false;
+  long multi_counter = -1;
+  const long n_multi = n + 2 - (n % 3 == 2 ? 1 : 0);  // never divisible by 3
+  if (std::getenv("SMMC_DEVICE_MAP")) {
+    multi_ran = true;
+    std::vector<float> one, three;
+    mc_simulations_gpu(counter, n_multi, periods, 1000.f, table, one, 1);
+    mc_simulations_gpu(counter, n_multi, periods, 1000.f, table, three, 3);
+    multi_counter = counter;
+    multi_same = one.size() == size_t(n_multi) && one == three;
+    smmc::Summary s1 = smmc::mc_summary(n_multi, periods, 1000.f, false, table, 0.f, 0.f, 1000.f, 64, 0.f, 8000.f, 1);
+    smmc::Summary s3 = smmc::mc_summary(n_multi, periods, 1000.f, false, table, 0.f, 0.f, 1000.f, 64, 0.f, 8000.f, 3);
+    multi_summary_same = s1.count == std::uint64_t(n_multi) && s3.count == s1.count && s3.below == s1.below &&
+                         s3.hist == s1.hist && s3.underflow == s1.underflow && s3.overflow == s1.overflow &&
+                         s3.min == s1.min && s3.max == s1.max && std::fabs(s3.sum - s1.sum) <= 1e-12 * std::fabs(s1.sum) &&
+                         std::fabs(s3.sumsq - s1.sumsq) <= 1e-12 * std::fabs(s1.sumsq);
+  }
+
+  // progress granularity: a long run must be seen advancing in several steps by a polling thread
+  // (the reference advances n_simulations every 1000 paths, src/simulations.cpp:254)
+  size_t progress_steps = 0;
+  bool progress_monotone = true;
+  {
+    const long n_big = 24000000;
+    std::vector<float> big(n_big);
+    std::atomic<long> cbig{0};
+    std::atomic<bool> done{false};
+    std::set<long> seen;
+    std::thread poll([&] {
+      long prev = 0;
+      while (!done) {
+        const long c = cbig;
+        if (c < prev) progress_monotone = false;
+        prev = c;
+        if (c > 0 && c < n_big) seen.insert(c);
+        std::this_thread::yield();
+      }
+    });
+    mc_simulations(cbig, n_big, 8u, 1000.f, table, big);
+    done = true;
+    poll.join();
+    progress_steps = seen.size();
+    progress_monotone = progress_monotone && cbig == n_big;
+  }
+
+  // update_mean_std on a large offset with a small spread (the one-pass variance must be formed
+  // from the double mean), and on an all-equal vector (std exactly 0, never NaN)
+  float lv_mean = 0, lv_std = 0, eq_mean = 0, eq_std = -1;
+  {
+    std::vector<float> lv(1000000), eq(100000, 1000.013f);
+    for (size_t i = 0; i < lv.size(); ++i) lv[i] = 1000.013f + 0.05f * std::sin(0.001f * float(i));
+    smmc::update_mean_std(lv_mean, lv_std, lv, long(lv.size()));
+    smmc::update_mean_std(eq_mean, eq_std, eq, long(eq.size()));
+  }
+
   std::printf("{\"concurrent_ok\": %s, ", concurrent_ok ? "true" : "false");
+  std::printf("\"multi_ran\": %s, \"multi_same\": %s, \"multi_summary_same\": %s, \"multi_counter\": %ld, \"n_multi\": %ld, ",
+              multi_ran ? "true" : "false", multi_same ? "true" : "false", multi_summary_same ? "true" : "false",
+              multi_counter, n_multi);
+  std::printf("\"progress_steps\": %zu, \"progress_monotone\": %s, \"lv_mean\": %.9g, \"lv_std\": %.9g, "
+              "\"eq_mean\": %.9g, \"eq_std\": %.9g, ",
+              progress_steps, progress_monotone ? "true" : "false", lv_mean, lv_std, eq_mean, eq_std);
   std::printf("\"quart\": [%.9g, %.9g, %.9g, %.9g, %.9g], \"hmean\": %.9g, \"hstd\": %.9g, \"hbelow\": %ld, \"ramp_mean\": %.9g, ",
               quart[0], quart[1], quart[2], quart[3], quart[4], hmean, hstd, hbelow, ramp_mean);
   std::printf("\"n\": %ld, \"gpu_hash\": %" PRIu64 ", \"cpu_hash\": %" PRIu64 ", \"counter_gpu\": %ld, \"seen_mid\": %ld, "

@@ -32,7 +32,8 @@ def test_no_gpu_is_a_loud_error_not_a_cpu_run():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     r = subprocess.run([os.path.join(BIN, "benchmark_mc_gpu"), "1", "360", "1000"], capture_output=True, text=True, cwd=ROOT)
-    assert r.returncode == 1 and "no HIP device visible" in r.stderr
+    assert r.returncode == 1 and ("no HIP device visible" in r.stderr or "no MI355X visible" in r.stderr)
+    assert "no CPU fallback" in r.stderr
 
 
 def test_dropin_header_is_self_contained(tmp_path):

@@ -35,8 +35,20 @@ def built():
 def test_cpp_dropin_matches_python_path_and_oracle(built, oracle, table):
     import stock_market_monte_carlo_amd as S
     n, p = 20000, 36
-    out = subprocess.check_output([built, str(n), str(p)], cwd=ROOT)
+    # SMMC_DEVICE_MAP: the three shards of the n_gpus = 3 calls all run on this box's one GPU
+    out = subprocess.check_output([built, str(n), str(p)], cwd=ROOT, env=dict(os.environ, SMMC_DEVICE_MAP="0,0,0"))
     d = json.loads(out.decode().strip().splitlines()[-1])
+    # the multi-shard host path (thread fan-out, one engine per shard, host merge in shard order)
+    assert d["multi_ran"] and d["multi_same"] and d["multi_summary_same"]
+    assert d["multi_counter"] == d["n_multi"] and d["n_multi"] % 3 != 0
+    # a polling thread sees a long run advance in steps (n/16-path chunks), never backwards
+    assert d["progress_steps"] >= 4 and d["progress_monotone"]
+    # one-pass variance at a large offset / on equal values (was 0.18 and NaN-prone)
+    lv = (np.float32(1000.013) + np.float32(0.05) * np.sin(np.float32(0.001) * np.arange(1000000, dtype=np.float32))).astype(np.float32)
+    assert d["lv_std"] == pytest.approx(float(lv.astype(np.float64).std()), rel=1e-4)
+    assert d["lv_mean"] == pytest.approx(float(lv.astype(np.float64).mean()), rel=1e-7)
+    # equal values: the double sums round at ~1e-16 relative, so up to ~1e-5 may be left; never NaN
+    assert 0.0 <= d["eq_std"] < 2e-4 and d["eq_mean"] == pytest.approx(1000.013, rel=1e-7)
     want = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, p, n, 4242, table=table))["final"]
     assert d["gpu_hash"] == fnv(want) == d["cpu_hash"]            # both reference signatures, same stream
     assert d["gpu_hash"] == fnv(S.mc_simulations_gpu(n, p, 1000.0, table, seed=4242))
@@ -86,6 +98,37 @@ def test_benchmark_mc_gpu_cli_prints_reference_lines(built, oracle, table):
     # Gaussian mode through the same program
     r = _run("benchmark_mc_gpu", 1, 360, 100000, env={"SMMC_MODE": "gaussian", "SMMC_JSON": "1"})
     assert r.returncode == 0 and '"program": "benchmark_mc_gpu"' in r.stdout
+
+
+def test_benchmark_mc_gpu_three_shards_on_one_gpu(built):
+    """`benchmark_mc_gpu 3 360 100003` (reference: n_gpus is just argv[1], examples/benchmark_mc_gpu.cpp:52)
+    through the C++ multi-shard path; SMMC_DEVICE_MAP puts the three shards on the one GPU here."""
+    one = _run("benchmark_mc_gpu", 1, 360, 100003, env={"SMMC_JSON": "1"})
+    three = _run("benchmark_mc_gpu", 3, 360, 100003, env={"SMMC_DEVICE_MAP": "0,0,0", "SMMC_JSON": "1", "SMMC_VERBOSE": "1"})
+    assert one.returncode == 0 and three.returncode == 0, three.stderr
+    pick = lambda out: [l for l in out.splitlines() if l.startswith("mean:") or l.startswith("count_below")]  # noqa: E731
+    assert pick(one.stdout) == pick(three.stdout) and len(pick(one.stdout)) == 2
+    assert "All 100003 simulation done" in three.stdout
+    assert three.stderr.count("smmc: shard") == 3 and "paths [66669, 100003)" in three.stderr
+    # without the map, 3 shards on a 1-GPU box is the reference's error case (more GPUs than present)
+    import torch
+    if torch.cuda.device_count() < 3:
+        r = _run("benchmark_mc_gpu", 3, 360, 1000)
+        assert r.returncode == 1 and "exceeds the visible devices" in r.stderr
+
+
+def test_python_mc_simulations_gpu_shards_concurrently(table, monkeypatch):
+    import stock_market_monte_carlo_amd as S
+    monkeypatch.setenv("SMMC_DEVICE_MAP", "0,0,0")
+    n = 300007
+    one = S.mc_simulations_gpu(n, 24, 1000.0, table, n_gpus=1, seed=5)
+    three = S.mc_simulations_gpu(n, 24, 1000.0, table, n_gpus=3, seed=5)
+    assert np.array_equal(one.view(np.uint32), three.view(np.uint32))
+    monkeypatch.delenv("SMMC_DEVICE_MAP")
+    import torch
+    if torch.cuda.device_count() < 3:
+        with pytest.raises(ValueError):
+            S.mc_simulations_gpu(n, 24, 1000.0, table, n_gpus=3, seed=5)
 
 
 def test_other_clis_run(built):
