@@ -145,8 +145,7 @@ def cpu_baseline(table, budget_s=12.0, n_periods=N_PERIODS):
     # variant (i) of SURVEY 8d: as the reference does it, a fresh std::random_device seeding a fresh
     # mt19937 for EVERY path (src/simulations.cpp:245-247) -- set-up dominated and OS dependent
     try:
-        nr = max(1000, int(min(n, n / dt * 4.0)))  # ~4 s if it ran at the deterministic rate; it will not
-        nr -= nr % 1000
+        nr = 20_000  # grown until it runs >= 3 s: the per-path cost is OS dependent (4-45 us measured)
         while True:
             t0 = time.perf_counter()
             O.asref_mc_simulations(nr, n_periods, 1000.0, table, n_threads=threads)
@@ -273,8 +272,9 @@ def launch_ranks(n_ranks, argv):
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p.kill()
-    sys.stdout.write(out0.decode(errors="replace"))
-    sys.stdout.flush()
+    # ONE JSON line on stdout; whatever else rank 0 printed there (gloo's connection banner) goes to stderr
+    for line in out0.decode(errors="replace").splitlines():
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
     return rc
 
 

@@ -526,6 +526,8 @@ static int cmp_float(const void *a, const void *b) {
 /* k-th smallest (0-based) by fully sorting a copy -- what examples/visualize_returns_gpu.cpp:
  * 108-109 does with std::sort (and :83-111 of the cpu_v2 twin with std::nth_element). */
 ORC_API int orc_order_statistics(const float *v, uint64_t n, const uint64_t *ranks, uint32_t n_ranks, float *out) {
+  for (uint32_t q = 0; q < n_ranks; q++)
+    if (ranks[q] >= n) return -1;  /* found by the ASan driver (oracle/sanitize): was an out-of-bounds read */
   float *copy = (float *)malloc(sizeof(float) * (size_t)(n ? n : 1));
   if (!copy) return -2;
   memcpy(copy, v, sizeof(float) * (size_t)n);

@@ -8,6 +8,12 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsmmc_hip.so")
+# Development only: tools/variant_build.sh writes experimental builds under _build/ (never over the
+# product library) and the A/B tools point this at them.
+if os.environ.get("SMMC_LIB"):
+    import sys as _sys
+    LIB_PATH = os.path.abspath(os.environ["SMMC_LIB"])
+    print(f"stock_market_monte_carlo_amd: DEVELOPMENT library {LIB_PATH} (SMMC_LIB)", file=_sys.stderr)
 
 ABI_VERSION = 2
 MODE_TABLE = 0

@@ -104,7 +104,7 @@ int main(int argc, char **argv) {
   // so the result must not depend on the split; the N mod 3 remainder is kept (src/simulations.cu:602-603 drops it)
   bool multi_ran = false, multi_same = false, multi_summary_same = false;
   long multi_counter = -1;
-  const long n_multi = n + 2 - (n % 3 == 2 ? 1 : 0);  // never divisible by 3
+  const long n_multi = (n + 1) % 3 ? n + 1 : n + 2;  // never divisible by 3
   if (std::getenv("SMMC_DEVICE_MAP")) {
     multi_ran = true;
     std::vector<float> one, three;

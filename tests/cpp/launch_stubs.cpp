@@ -1,0 +1,20 @@
+// launch_stubs.cpp -- CPU sanitizer builds only (make -C oracle asan / tsan): stands in for the two
+// HIP translation units of THIS repository (csrc/smmc_kernels.hip, smmc_stats_kernels.hip), whose device
+// code g++ cannot compile, so that the host-side product code (csrc/smmc_capi.cpp, smmc_dropin.cpp) links
+// and its no-GPU paths can run under ASan / UBSan / TSan.  Every launch reports "no device".
+#include "smmc_internal.h"
+
+namespace smmc {
+hipError_t launch_values_stats(const ValuesArgs &, uint32_t, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_radix_hist(const float *, uint64_t, int, uint32_t, const SelectState *, unsigned long long *, uint32_t,
+                             hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_radix_pick(int, uint32_t, SelectState *, const unsigned long long *, float *, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_paths(const KernelArgs &, int, uint32_t, size_t, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_finalize(const BlockPartial *, uint32_t, smmc_stats *, uint32_t, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_keepdata(const KernelArgs &, bool, int, int, uint32_t, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_selftest(uint32_t, uint32_t, unsigned long long *, uint32_t, hipStream_t) { return hipErrorNoDevice; }
+uint32_t values_hist_copies(uint32_t) { return 1; }
+size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins) { return (static_cast<size_t>(table_len) + n_bins) * 4u; }
+size_t keepdata_lds_bytes(uint32_t, int, int) { return 0; }
+size_t bm_tables_bytes() { return (1056 * 4 + 256 * 2) * 4; }
+}  // namespace smmc
