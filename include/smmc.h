@@ -128,6 +128,14 @@ void smmc_engine_destroy(smmc_engine *e);
  * handle launches go to (so a caller can order its own streams against an engine-owned one). */
 int smmc_engine_set_stream(smmc_engine *e, void *stream);
 int smmc_engine_get_stream(smmc_engine *e, void **stream);
+/* Ordering against another stream of the same device, for engines that keep their own stream:
+ * wait_stream -- what the engine enqueues from now on runs after everything enqueued on `stream`
+ * so far (call it before launching into buffers that were allocated or written on `stream`);
+ * release_to_stream -- what is enqueued on `stream` from now on runs after everything the engine has
+ * enqueued so far (call it before `stream` reads, frees or reuses the outputs).  Event-based, no
+ * host synchronisation. */
+int smmc_engine_wait_stream(smmc_engine *e, void *stream);
+int smmc_engine_release_to_stream(smmc_engine *e, void *stream);
 
 /* Uploads the historical-returns table (percent units, host memory).  Replaces
  * the H2D table copies at src/simulations.cu:382,451,525,617.  Waits for work already
@@ -177,10 +185,11 @@ int smmc_engine_set_progress(smmc_engine *e, smmc_progress_fn fn, void *user);
  *                    chunk (the n_simulations counter of src/simulations.cpp:254); when it or a
  *                    progress callback is given, chunks shrink to about n_paths / 16 (at least
  *                    2^20 paths) so that a poller sees the run advance
- * Environment: SMMC_PIN_HOST=whole|chunk page-locks host_final (hipHostRegister) for the call when
- * it is not pinned already -- whole buffer up front, or chunk by chunk one chunk ahead of the
- * copies; default off (registration costs more than it saves on a single run);
- * SMMC_HOST_CHUNK_PATHS overrides the chunk length.  Results never depend on either.
+ * Environment: SMMC_PIN_HOST=whole|chunk|0: a host_final of 32 MiB or more that is not pinned
+ * already is page-locked (hipHostRegister) for the duration of the call -- the whole buffer up front
+ * (default: registration runs at 25-75 GB/s and lets the copies overlap the kernels), or chunk by
+ * chunk one chunk ahead of the copies, or not at all; a failed registration silently falls back to
+ * the pageable copy.  SMMC_HOST_CHUNK_PATHS overrides the chunk length.  Results never depend on either.
  *   stats, hist      merged statistics header and n_bins bucket counts
  * Synchronous. */
 int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *host_final,

@@ -74,6 +74,8 @@ SYMBOLS = [
     ("smmc_engine_destroy", None, [C.c_void_p]),
     ("smmc_engine_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("smmc_engine_get_stream", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("smmc_engine_wait_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("smmc_engine_release_to_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("smmc_engine_set_progress", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("smmc_engine_set_table", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     ("smmc_engine_simulate", C.c_int,

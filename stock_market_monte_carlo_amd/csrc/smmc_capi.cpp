@@ -91,6 +91,7 @@ struct smmc_engine {
   size_t stage_stats_bytes = 0;
   hipEvent_t ev_compute[2] = {nullptr, nullptr};
   hipEvent_t ev_copy[2] = {nullptr, nullptr};
+  hipEvent_t ev_order = nullptr;  // smmc_engine_set_stream / wait_stream / release_to_stream
 
   // order statistics workspace
   smmc::SelectState *d_select = nullptr;
@@ -103,7 +104,7 @@ struct smmc_engine {
   size_t ev_used = 0;
 
   uint64_t host_chunk_paths = kHostChunkPaths;  // SMMC_HOST_CHUNK_PATHS
-  int pin_policy = 0;                           // SMMC_PIN_HOST: 0 never, 1 whole buffer, 2 chunk by chunk
+  int pin_policy = 1;                           // SMMC_PIN_HOST: 0 never, 1 whole buffer (default), 2 chunk by chunk
   uint64_t pin_min_bytes = 32ull << 20;
   smmc_progress_fn progress_fn = nullptr;
   void *progress_user = nullptr;
@@ -372,6 +373,7 @@ void smmc_engine_destroy(smmc_engine *e) {
     (void)hipStreamDestroy(e->copy_stream);
   }
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+  if (e->ev_order) (void)hipEventDestroy(e->ev_order);
   for (int i = 0; i < 2; ++i) {
     if (e->ev_compute[i]) (void)hipEventDestroy(e->ev_compute[i]);
     if (e->ev_copy[i]) (void)hipEventDestroy(e->ev_copy[i]);
@@ -588,8 +590,8 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
   };
   report(0);
 
-  // Pinning the caller's result buffer (SMMC_PIN_HOST, default off: see DESIGN.md section 6 for the
-  // measurements).  "whole": one hipHostRegister over all of host_final before the first chunk;
+  // Pinning the caller's result buffer (SMMC_PIN_HOST=whole|chunk|0; DESIGN.md section 6 has the
+  // measurements).  "whole" (default): one hipHostRegister over all of host_final before the first chunk;
   // "chunk": chunk c + 1 is registered by this host thread while chunk c computes, and chunk c is
   // released once its copy has finished.  Buffers that are pinned already are left alone.
   HostPin pin_all, pin_chunk[2];
@@ -888,9 +890,9 @@ int smmc_engine_set_stream(smmc_engine *e, void *stream) {
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
   // work already enqueued keeps its order: the new stream waits for the old one's tail (the
   // engine's workspace -- partials, staging -- is shared between consecutive launches)
-  if (!e->ev_compute[0]) SMMC_HIP(hipEventCreateWithFlags(&e->ev_compute[0], hipEventDisableTiming));
-  SMMC_HIP(hipEventRecord(e->ev_compute[0], e->stream));
-  SMMC_HIP(hipStreamWaitEvent(s, e->ev_compute[0], 0));
+  if (!e->ev_order) SMMC_HIP(hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming));
+  SMMC_HIP(hipEventRecord(e->ev_order, e->stream));
+  SMMC_HIP(hipStreamWaitEvent(s, e->ev_order, 0));
   if (e->own_stream) {
     SMMC_HIP(hipStreamSynchronize(e->stream));
     SMMC_HIP(hipStreamDestroy(e->stream));
@@ -903,6 +905,30 @@ int smmc_engine_set_stream(smmc_engine *e, void *stream) {
 int smmc_engine_get_stream(smmc_engine *e, void **stream) {
   if (!e || !stream) return fail(SMMC_ERR_INVALID, "NULL argument");
   *stream = static_cast<void *>(e->stream);
+  return SMMC_OK;
+}
+
+int smmc_engine_wait_stream(smmc_engine *e, void *stream) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  hipStream_t other = static_cast<hipStream_t>(stream);
+  if (other == e->stream) return SMMC_OK;
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  if (!e->ev_order) SMMC_HIP(hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming));
+  SMMC_HIP(hipEventRecord(e->ev_order, other));
+  SMMC_HIP(hipStreamWaitEvent(e->stream, e->ev_order, 0));
+  return SMMC_OK;
+}
+
+int smmc_engine_release_to_stream(smmc_engine *e, void *stream) {
+  if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  hipStream_t other = static_cast<hipStream_t>(stream);
+  if (other == e->stream) return SMMC_OK;
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  if (!e->ev_order) SMMC_HIP(hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming));
+  SMMC_HIP(hipEventRecord(e->ev_order, e->stream));
+  SMMC_HIP(hipStreamWaitEvent(other, e->ev_order, 0));
   return SMMC_OK;
 }
 

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <filesystem>
 #include <fstream>
 #include <map>
@@ -21,7 +22,14 @@
 #include <thread>
 #include <utility>
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include "smmc.h"
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23  // Linux 5.14
+#endif
 
 namespace {
 
@@ -220,6 +228,68 @@ void run_final_values(std::atomic<long> &n_simulations, long n_total, unsigned p
   n_simulations = n_total;  // src/simulations.cu:678
 }
 
+// Sizes `v` to n floats with its pages already resident.  A fresh 400 MB vector costs one page
+// fault per 4 KiB when resize() zero-fills it (65-120 ms measured on the GPU box's host: more than
+// the whole simulation).  So: reserve, have the kernel map the new allocation from several threads
+// (madvise MADV_POPULATE_WRITE: no user-space write into unconstructed storage), then resize --
+// value-initialisation then runs at memset speed.  Any failure of the hint is ignored.
+void resize_prefaulted(std::vector<float> &v, size_t n) {
+  if (n > v.capacity() && n >= (size_t(8) << 20)) {
+    v.clear();  // nothing to carry over into the new allocation: the callee replaces the contents
+    v.reserve(n);
+    const long page = sysconf(_SC_PAGESIZE);
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(v.data()) + page - 1) / page * page;
+    const uintptr_t hi = reinterpret_cast<uintptr_t>(v.data() + n) / page * page;
+    if (page > 0 && hi > lo) {
+      const size_t bytes = hi - lo;
+      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+      const size_t want = std::min<size_t>(std::min<size_t>(8, hw), std::max<size_t>(1, bytes >> 25));
+      const size_t per = (bytes / want + page - 1) / page * page;
+      std::vector<std::thread> workers;
+      for (size_t t = 0; t < want; ++t) {
+        const uintptr_t a = lo + t * per, b = std::min<uintptr_t>(hi, a + per);
+        if (a >= b) break;
+        workers.emplace_back([a, b] { (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_POPULATE_WRITE); });
+      }
+      for (auto &w : workers) w.join();
+    }
+  }
+  v.resize(n);
+}
+
+// Creates (and caches) the engine of every shard of an n_gpus-way call with `table` loaded, so that
+// the HIP runtime start-up and the first allocations overlap the sizing of the result vector.
+void warm_engines(long n_total, int n_gpus, const std::vector<float> *table) {
+  for_each_shard(n_total, n_gpus, [&](const Shard &sh) { Session ses(sh.device, table, sh.lane); });
+}
+
+// The callee-sized result of mc_simulations_gpu (src/simulations.cu:643-644): sized on a helper thread
+// while this one brings the engines up.
+void size_result_and_warm(std::vector<float> &totals, long n_total, int n_gpus, const std::vector<float> *table) {
+  const auto t0 = std::chrono::steady_clock::now();
+  std::exception_ptr sizing_error;
+  std::thread sizing([&] {
+    try {
+      resize_prefaulted(totals, static_cast<size_t>(n_total));
+    } catch (...) {
+      sizing_error = std::current_exception();
+    }
+  });
+  std::exception_ptr warm_error;
+  try {
+    warm_engines(n_total, n_gpus, table);
+  } catch (...) {
+    warm_error = std::current_exception();
+  }
+  const double t_warm = seconds_since(t0);
+  sizing.join();
+  if (verbose())
+    std::fprintf(stderr, "smmc: engines up in %.3f s, result vector (%ld floats) sized in %.3f s (overlapped)\n", t_warm, n_total,
+                 seconds_since(t0));
+  if (warm_error) std::rethrow_exception(warm_error);
+  if (sizing_error) std::rethrow_exception(sizing_error);
+}
+
 }  // namespace
 
 // ---- compounding core --------------------------------------------------------------------
@@ -341,7 +411,7 @@ void mc_simulations_gpu(std::atomic<long> &n_simulations, long max_n_simulations
                         float initial_capital, std::vector<float> &returns, std::vector<float> &totals,
                         int n_gpus) {
   if (max_n_simulations < 0 || n_periods < 0) throw std::invalid_argument("smmc: negative size");
-  totals.resize(static_cast<size_t>(max_n_simulations));  // callee-owned result, src/simulations.cu:643-644
+  size_result_and_warm(totals, max_n_simulations, n_gpus, &returns);  // callee-owned result, src/simulations.cu:643-644
   run_final_values(n_simulations, max_n_simulations, static_cast<unsigned>(n_periods), initial_capital,
                    SMMC_MODE_TABLE, &returns, 0.f, 0.f, totals.data(), n_gpus);
 }
@@ -441,7 +511,7 @@ void mc_simulations_gpu_gaussian(std::atomic<long> &n_simulations, long max_n_si
                                  float initial_capital, float return_mean, float return_std,
                                  std::vector<float> &totals, int n_gpus) {
   if (max_n_simulations < 0 || n_periods < 0) throw std::invalid_argument("smmc: negative size");
-  totals.resize(static_cast<size_t>(max_n_simulations));
+  size_result_and_warm(totals, max_n_simulations, n_gpus, nullptr);
   run_final_values(n_simulations, max_n_simulations, static_cast<unsigned>(n_periods), initial_capital,
                    SMMC_MODE_GAUSSIAN, nullptr, return_mean, return_std, totals.data(), n_gpus);
 }

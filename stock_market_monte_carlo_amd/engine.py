@@ -96,33 +96,26 @@ class Engine:
         _lib.check(self._L.smmc_engine_create(self.device, C.c_void_p(sp), C.byref(h)))
         self._h = h
         self.table_len = 0
-        self._ext = None
-        if self.own_stream:
-            # torch's view of the engine-owned stream: lets torch-allocated outputs be ordered against it
-            raw = C.c_void_p()
-            _lib.check(self._L.smmc_engine_get_stream(self._h, C.byref(raw)))
-            self._ext = torch.cuda.ExternalStream(raw.value, device=self.tdevice)
 
     # -- stream discipline ---------------------------------------------------
     def _enter(self):
         """Before enqueuing: launches go to the caller's CURRENT torch stream (a "torch" engine
         re-binds on every call: the caller may be inside `with torch.cuda.stream(s)` now), or the
         engine's own stream first waits for it (its outputs were just allocated there)."""
-        cur = self._torch.cuda.current_stream(self.tdevice)
+        cur = int(self._torch.cuda.current_stream(self.tdevice).cuda_stream)
         if self.follow_torch:
-            _lib.check(self._L.smmc_engine_set_stream(self._h, C.c_void_p(int(cur.cuda_stream))))
-        elif self._ext is not None:
-            self._ext.wait_stream(cur)
+            _lib.check(self._L.smmc_engine_set_stream(self._h, C.c_void_p(cur)))
+        elif self.own_stream:
+            _lib.check(self._L.smmc_engine_wait_stream(self._h, C.c_void_p(cur)))
         return cur
 
     def _leave(self, cur, *tensors):
-        """After enqueuing on an engine-owned stream: torch's current stream waits for the results,
-        and the caching allocator learns that the engine stream uses these blocks."""
-        if self._ext is not None:
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(self._ext)
-            cur.wait_stream(self._ext)
+        """After enqueuing on an engine-owned stream: torch's current stream waits for the engine's
+        work, so whatever torch does next with the outputs there -- read, free, reuse the block --
+        is ordered after the kernels that wrote them (no record_stream: the caching allocator would
+        poll events on a stream the engine may already have destroyed)."""
+        if self.own_stream:
+            _lib.check(self._L.smmc_engine_release_to_stream(self._h, C.c_void_p(cur)))
 
     def close(self):
         if getattr(self, "_h", None):

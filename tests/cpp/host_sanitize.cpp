@@ -107,6 +107,14 @@ static void no_device_paths() {
   try { mc_simulations(counter, 10, 5u, 1000.f, table, out); } catch (const std::runtime_error &) { ++thrown; }
   try { mc_simulations_gpu(counter, 10, 5, 1000.f, table, out, 1); } catch (const std::runtime_error &) { ++thrown; }
   try { mc_simulations_gpu(counter, 10, 5, 1000.f, table, out, 2); } catch (const std::runtime_error &) { ++thrown; }
+  {
+    // 12 MB result: the pre-faulting path of the callee-sized vector runs (on its helper thread) before
+    // the missing device is reported; the vector is sized and zeroed either way
+    std::vector<float> big;
+    try { mc_simulations_gpu(counter, 3000000, 5, 1000.f, table, big, 1); } catch (const std::runtime_error &) { ++thrown; }
+    EXPECT(big.size() == 3000000 && big.front() == 0.f && big.back() == 0.f);
+    --thrown;  // keeps the count below at the number of distinct entry points
+  }
   try { mc_simulations_gpu_reduceBlock(counter, 10, 5, 1000.f, table, means, vars, 1); } catch (const std::runtime_error &) { ++thrown; }
   try { mc_simulations_keepdata(counter, 10, 5u, 1000.f, table, data, out); } catch (const std::runtime_error &) { ++thrown; }
   try { reduce_mean_gpu(out, 10); } catch (const std::runtime_error &) { ++thrown; }
