@@ -229,29 +229,24 @@ void run_final_values(std::atomic<long> &n_simulations, long n_total, unsigned p
 }
 
 // Sizes `v` to n floats with its pages already resident.  A fresh 400 MB vector costs one page
-// fault per 4 KiB when resize() zero-fills it (65-120 ms measured on the GPU box's host: more than
-// the whole simulation).  So: reserve, have the kernel map the new allocation from several threads
-// (madvise MADV_POPULATE_WRITE: no user-space write into unconstructed storage), then resize --
-// value-initialisation then runs at memset speed.  Any failure of the hint is ignored.
-void resize_prefaulted(std::vector<float> &v, size_t n) {
-  if (n > v.capacity() && n >= (size_t(8) << 20)) {
-    v.clear();  // nothing to carry over into the new allocation: the callee replaces the contents
+// fault per 4 KiB when resize() zero-fills it (60-120 ms measured on the GPU box's host: more than
+// the whole simulation).  So: reserve, have the kernel map the new allocation (madvise
+// MADV_POPULATE_WRITE: no user-space write into unconstructed storage), then resize -- the
+// value-initialisation then runs at memset speed.  Measured for 400 MB (tools/ubench_hostreg.cpp):
+// plain resize 60 ms; populate from 1 / 2 / 4 / 8 threads + resize 28 / 17 / 24 / 20 ms: two threads.
+// Any failure of the hint is ignored.
+void resize_prefaulted_impl(std::vector<float> &v, size_t n) {
+  v.clear();  // the result replaces the contents (src/simulations.cu:643-644): nothing to carry over
+  if (n > v.capacity() && n * sizeof(float) >= (size_t(8) << 20)) {
     v.reserve(n);
     const long page = sysconf(_SC_PAGESIZE);
     const uintptr_t lo = (reinterpret_cast<uintptr_t>(v.data()) + page - 1) / page * page;
     const uintptr_t hi = reinterpret_cast<uintptr_t>(v.data() + n) / page * page;
     if (page > 0 && hi > lo) {
-      const size_t bytes = hi - lo;
-      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-      const size_t want = std::min<size_t>(std::min<size_t>(8, hw), std::max<size_t>(1, bytes >> 25));
-      const size_t per = (bytes / want + page - 1) / page * page;
-      std::vector<std::thread> workers;
-      for (size_t t = 0; t < want; ++t) {
-        const uintptr_t a = lo + t * per, b = std::min<uintptr_t>(hi, a + per);
-        if (a >= b) break;
-        workers.emplace_back([a, b] { (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_POPULATE_WRITE); });
-      }
-      for (auto &w : workers) w.join();
+      const uintptr_t mid = lo + (hi - lo) / 2 / page * page;
+      std::thread upper([mid, hi] { (void)madvise(reinterpret_cast<void *>(mid), hi - mid, MADV_POPULATE_WRITE); });
+      if (mid > lo) (void)madvise(reinterpret_cast<void *>(lo), mid - lo, MADV_POPULATE_WRITE);
+      upper.join();
     }
   }
   v.resize(n);
@@ -263,31 +258,18 @@ void warm_engines(long n_total, int n_gpus, const std::vector<float> *table) {
   for_each_shard(n_total, n_gpus, [&](const Shard &sh) { Session ses(sh.device, table, sh.lane); });
 }
 
-// The callee-sized result of mc_simulations_gpu (src/simulations.cu:643-644): sized on a helper thread
-// while this one brings the engines up.
+// The callee-sized result of mc_simulations_gpu (src/simulations.cu:643-644).  The engines come up
+// first and the vector is sized after, not beside them: with both at once the HIP runtime's start-up
+// (which maps memory) and the page population fight over the process's mmap lock (engines 35 ms alone,
+// 190-250 ms beside the population).
 void size_result_and_warm(std::vector<float> &totals, long n_total, int n_gpus, const std::vector<float> *table) {
   const auto t0 = std::chrono::steady_clock::now();
-  std::exception_ptr sizing_error;
-  std::thread sizing([&] {
-    try {
-      resize_prefaulted(totals, static_cast<size_t>(n_total));
-    } catch (...) {
-      sizing_error = std::current_exception();
-    }
-  });
-  std::exception_ptr warm_error;
-  try {
-    warm_engines(n_total, n_gpus, table);
-  } catch (...) {
-    warm_error = std::current_exception();
-  }
+  warm_engines(n_total, n_gpus, table);
   const double t_warm = seconds_since(t0);
-  sizing.join();
+  resize_prefaulted_impl(totals, static_cast<size_t>(n_total));
   if (verbose())
-    std::fprintf(stderr, "smmc: engines up in %.3f s, result vector (%ld floats) sized in %.3f s (overlapped)\n", t_warm, n_total,
-                 seconds_since(t0));
-  if (warm_error) std::rethrow_exception(warm_error);
-  if (sizing_error) std::rethrow_exception(sizing_error);
+    std::fprintf(stderr, "smmc: engines up in %.3f s, result vector (%ld floats) sized in %.3f s\n", t_warm, n_total,
+                 seconds_since(t0) - t_warm);
 }
 
 }  // namespace
@@ -500,6 +482,8 @@ long update_count_below_min(float &min_final_amount, const std::vector<float> &f
   summary_of(final_values, n_simulations, min_final_amount, &st, nullptr);
   return static_cast<long>(st.below);
 }
+
+void resize_prefaulted(std::vector<float> &v, std::size_t n) { resize_prefaulted_impl(v, n); }
 
 void fix_seed(bool fixed, std::uint64_t seed) {
   std::lock_guard<std::mutex> lock(g_seed_mutex);

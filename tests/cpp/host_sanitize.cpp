@@ -72,6 +72,18 @@ static void csv_round_trip(int id) {
   EXPECT(smmc::bundled_synthetic_returns().size() == 1127);
 }
 
+static void sizing() {
+  // the callee-sized result vector of mc_simulations_gpu: pre-faulted from two threads, then resized
+  std::vector<float> big = {1.f, 2.f};
+  smmc::resize_prefaulted(big, 3000001);  // 12 MB: above the threshold of the madvise path
+  EXPECT(big.size() == 3000001 && big.front() == 0.f && big[1500000] == 0.f && big.back() == 0.f);
+  big[7] = 5.f;
+  smmc::resize_prefaulted(big, 100);  // small sizes: no madvise; always n zeros
+  EXPECT(big.size() == 100 && big[7] == 0.f);
+  smmc::resize_prefaulted(big, 0);
+  EXPECT(big.empty());
+}
+
 static void samplers(unsigned seed) {
   std::vector<float> table = smmc::bundled_synthetic_returns();
   smmc::fix_seed(true, seed);
@@ -107,14 +119,6 @@ static void no_device_paths() {
   try { mc_simulations(counter, 10, 5u, 1000.f, table, out); } catch (const std::runtime_error &) { ++thrown; }
   try { mc_simulations_gpu(counter, 10, 5, 1000.f, table, out, 1); } catch (const std::runtime_error &) { ++thrown; }
   try { mc_simulations_gpu(counter, 10, 5, 1000.f, table, out, 2); } catch (const std::runtime_error &) { ++thrown; }
-  {
-    // 12 MB result: the pre-faulting path of the callee-sized vector runs (on its helper thread) before
-    // the missing device is reported; the vector is sized and zeroed either way
-    std::vector<float> big;
-    try { mc_simulations_gpu(counter, 3000000, 5, 1000.f, table, big, 1); } catch (const std::runtime_error &) { ++thrown; }
-    EXPECT(big.size() == 3000000 && big.front() == 0.f && big.back() == 0.f);
-    --thrown;  // keeps the count below at the number of distinct entry points
-  }
   try { mc_simulations_gpu_reduceBlock(counter, 10, 5, 1000.f, table, means, vars, 1); } catch (const std::runtime_error &) { ++thrown; }
   try { mc_simulations_keepdata(counter, 10, 5u, 1000.f, table, data, out); } catch (const std::runtime_error &) { ++thrown; }
   try { reduce_mean_gpu(out, 10); } catch (const std::runtime_error &) { ++thrown; }
@@ -132,6 +136,7 @@ int main() {
   scalars_and_records();
   csv_round_trip(0);
   samplers(1);
+  sizing();
   no_device_paths();
   // the same from four threads at once
   std::vector<std::thread> threads;
@@ -141,6 +146,7 @@ int main() {
         scalars_and_records();
         csv_round_trip(t + 1);
         samplers(100 + t);
+        sizing();
         no_device_paths();
       }
     });

@@ -6,7 +6,13 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
+#include <sys/mman.h>
+#include <unistd.h>
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s failed: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char **argv) {
@@ -47,6 +53,30 @@ int main(int argc, char **argv) {
     treg = now() - t0;
     std::printf("[%d] register in %zu x 64 MiB  %8.2f ms  (%.2f ms per piece)\n", rep, k, treg * 1e3, treg * 1e3 / k);
     for (size_t off = 0; off < bytes; off += piece) CK(hipHostUnregister(reinterpret_cast<char *>(v.data()) + off));
+  }
+  // sizing a fresh vector: plain resize vs reserve + MADV_POPULATE_WRITE from T threads + resize
+  for (int threads : {0, 1, 2, 4, 8, 16}) {
+    t0 = now();
+    std::vector<float> v;
+    double t_pop = 0;
+    if (threads) {
+      v.reserve(n);
+      const long page = sysconf(_SC_PAGESIZE);
+      const uintptr_t lo = (reinterpret_cast<uintptr_t>(v.data()) + page - 1) / page * page;
+      const uintptr_t hi = reinterpret_cast<uintptr_t>(v.data() + n) / page * page;
+      const size_t per = ((hi - lo) / threads + page - 1) / page * page;
+      std::vector<std::thread> w;
+      int rc_all = 0;
+      for (int t = 0; t < threads; ++t) {
+        const uintptr_t a = lo + t * per, b = std::min<uintptr_t>(hi, a + per);
+        if (a < b) w.emplace_back([a, b, &rc_all] { if (madvise(reinterpret_cast<void *>(a), b - a, MADV_POPULATE_WRITE)) rc_all = 1; });
+      }
+      for (auto &x : w) x.join();
+      t_pop = now() - t0;
+      if (rc_all) std::printf("   (madvise failed)\n");
+    }
+    v.resize(n);
+    std::printf("size vector: %2d populate threads: populate %7.2f ms, total %7.2f ms\n", threads, t_pop * 1e3, (now() - t0) * 1e3);
   }
   // untouched memory: register first, let the copy be the first touch
   t0 = now();
