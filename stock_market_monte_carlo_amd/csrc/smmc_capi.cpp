@@ -447,42 +447,95 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   if (sim->n_periods >= (1u << 24)) return fail(SMMC_ERR_INVALID, "keepdata supports n_periods < 2^24");
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-  smmc::KernelArgs a = make_args(e, sim);
-  a.d_traj = d_traj;
-  a.d_final = d_final;
   if (sim->n_paths == 0) return SMMC_OK;
-  // tuning knobs, results do not depend on them: columns per LDS tile (16 | 32), waves per
-  // workgroup, workgroups per CU.  Defaults measured with tools/kd_ab.py: 32 columns (16 writes
-  // half lines); table mode 4 waves, three workgroups per CU (8 or 12 waves 1-5 % slower, 3 / 5 /
-  // 6 waves -- SIMDs unevenly filled -- 5-25 % slower); Gaussian mode, where the Box-Muller tables
-  // take 18.9 KB of every workgroup's LDS, one 12-wave workgroup per CU (2-15 % faster than two of
-  // 4); grid = what is resident (a wave strides over its 64-path chunks).
-  int tile = 32;
-  if (const char *env = std::getenv("SMMC_KEEPDATA_TILE")) {
-    const long v = std::strtol(env, nullptr, 10);
-    if (v == 16 || v == 32) tile = static_cast<int>(v);
-  }
-  const size_t lds_cu = 160u * 1024u;
-  const size_t fixed = smmc::keepdata_lds_bytes(a.table_len, tile, 0);
-  const size_t per_wave = smmc::keepdata_lds_bytes(a.table_len, tile, 1) - fixed;
-  const int fit = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 12)) : 0;
-  if (fit < 1) return fail(SMMC_ERR_INVALID, "keepdata: the table leaves no LDS for a tile");
-  int waves = sim->mode == SMMC_MODE_TABLE ? std::min(fit, 4) : (fit >= 12 ? 12 : fit >= 8 ? 8 : std::min(fit, 4));
-  if (const char *env = std::getenv("SMMC_KEEPDATA_WAVES")) {
-    const long v = std::strtol(env, nullptr, 10);
-    if (v >= 1 && v <= fit) waves = static_cast<int>(v);
-  }
-  const size_t lds = smmc::keepdata_lds_bytes(a.table_len, tile, waves);
-  const uint64_t n_wave_chunks = (sim->n_paths + 63) / 64;
-  const uint32_t resident = static_cast<uint32_t>(std::max<size_t>(lds_cu / lds, 1));
-  const uint32_t per_cu = e->keepdata_blocks_per_cu ? e->keepdata_blocks_per_cu : resident;
-  const uint32_t kgrid = static_cast<uint32_t>(
-      std::min<uint64_t>((n_wave_chunks + waves - 1) / waves, static_cast<uint64_t>(e->compute_units) * per_cu));
-  rc = timing_begin(e);
-  if (rc) return rc;
   float unused_lo, unused_hi;
   const bool exact_div = divide_kind(e, sim, false, &unused_lo, &unused_hi) != SMMC_DIV_FAST;
-  SMMC_HIP(smmc::launch_keepdata(a, exact_div, tile, waves, kgrid, e->stream));
+
+  // Two kernels (smmc_kernels.hip).  The comb form takes whole 2048-row super-chunks when the row
+  // length is odd by construction (n_periods a multiple of the draws per Philox block) and there is
+  // enough of it to fill the chip; the tile form takes the rest (< 2048 rows), or everything.
+  // SMMC_KEEPDATA_KERNEL=tile|comb forces one (results never depend on it).
+  const uint32_t draws = smmc::keepdata_draws(sim->mode == SMMC_MODE_TABLE ? e->table_len : 0u);
+  const uint64_t row_len = static_cast<uint64_t>(sim->n_periods) + 1;
+  uint64_t n_super = sim->n_paths / 2048u;
+  bool comb = sim->n_periods >= 64u && sim->n_periods % draws == 0u && row_len <= (1u << 20) &&
+              n_super >= static_cast<uint64_t>(e->compute_units) / 2u;
+  if (const char *env = std::getenv("SMMC_KEEPDATA_KERNEL")) {
+    if (!std::strcmp(env, "tile")) comb = false;
+    if (!std::strcmp(env, "comb")) comb = sim->n_periods >= 64u && sim->n_periods % draws == 0u && row_len <= (1u << 20) && n_super >= 1;
+  }
+  const uint64_t n_comb = comb ? n_super * 2048u : 0u;
+  rc = timing_begin(e);
+  if (rc) return rc;
+  if (comb) {
+    smmc::KernelArgs a = make_args(e, sim);
+    a.d_traj = d_traj;
+    a.d_final = nullptr;
+    a.n_paths = n_comb;
+    // waves per workgroup: what fits the CU's LDS beside the tables, one workgroup per CU
+    const size_t lds_cu = 160u * 1024u;
+    const size_t fixed = smmc::keepdata_comb_lds_bytes(a.table_len, 0);
+    const size_t per_wave = smmc::keepdata_comb_lds_bytes(a.table_len, 1) - fixed;
+    int waves = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 16)) : 0;
+    if (const char *env = std::getenv("SMMC_KEEPDATA_COMB_WAVES")) {  // tuning knob
+      const long v = std::strtol(env, nullptr, 10);
+      if (v >= 1 && v <= waves) waves = static_cast<int>(v);
+    }
+    if (waves < 1) return fail(SMMC_ERR_INVALID, "keepdata: the table leaves no LDS for a tile");
+    // rows per stream: 4 (1 % of extra columns at P = 360), fewer while that leaves waves without work
+    uint32_t k_rows = 4;
+    if (const char *env = std::getenv("SMMC_KEEPDATA_K")) {  // tuning knob: 1, 2, 4, 8, 16 or 32
+      const long v = std::strtol(env, nullptr, 10);
+      if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k_rows = static_cast<uint32_t>(v);
+    } else {
+      while (k_rows > 1 && n_super * (32u / k_rows) < 4ull * e->compute_units * static_cast<uint64_t>(waves)) k_rows /= 2;
+    }
+    const uint64_t n_wave_chunks = n_super * (32u / k_rows);
+    const uint32_t per_cu = e->keepdata_blocks_per_cu ? e->keepdata_blocks_per_cu : 1u;
+    const uint32_t cgrid = static_cast<uint32_t>(
+        std::min<uint64_t>((n_wave_chunks + waves - 1) / waves, static_cast<uint64_t>(e->compute_units) * per_cu));
+    SMMC_HIP(smmc::launch_keepdata_comb(a, exact_div, k_rows, n_wave_chunks, sim->n_paths, waves, cgrid, e->stream));
+  }
+  if (n_comb < sim->n_paths) {
+    smmc_sim rest = *sim;
+    rest.first_path = sim->first_path + n_comb;
+    rest.n_paths = sim->n_paths - n_comb;
+    smmc::KernelArgs a = make_args(e, &rest);
+    a.d_traj = d_traj + n_comb * row_len;
+    a.d_final = (d_final && !comb) ? d_final : nullptr;
+    // tuning knobs, results do not depend on them: columns per LDS tile (16 | 32), waves per
+    // workgroup, workgroups per CU.  Defaults measured with tools/kd_ab.py: 32 columns (16 writes
+    // half lines); table mode 4 waves, three workgroups per CU (8 or 12 waves 1-5 % slower, 3 / 5 /
+    // 6 waves -- SIMDs unevenly filled -- 5-25 % slower); Gaussian mode, where the Box-Muller tables
+    // take 18.9 KB of every workgroup's LDS, one 12-wave workgroup per CU (2-15 % faster than two of
+    // 4); grid = what is resident (a wave strides over its 64-path chunks).
+    int tile = 32;
+    if (const char *env = std::getenv("SMMC_KEEPDATA_TILE")) {
+      const long v = std::strtol(env, nullptr, 10);
+      if (v == 16 || v == 32) tile = static_cast<int>(v);
+    }
+    const size_t lds_cu = 160u * 1024u;
+    const size_t fixed = smmc::keepdata_lds_bytes(a.table_len, tile, 0);
+    const size_t per_wave = smmc::keepdata_lds_bytes(a.table_len, tile, 1) - fixed;
+    const int fit = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 12)) : 0;
+    if (fit < 1) return fail(SMMC_ERR_INVALID, "keepdata: the table leaves no LDS for a tile");
+    int waves = sim->mode == SMMC_MODE_TABLE ? std::min(fit, 4) : (fit >= 12 ? 12 : fit >= 8 ? 8 : std::min(fit, 4));
+    if (const char *env = std::getenv("SMMC_KEEPDATA_WAVES")) {
+      const long v = std::strtol(env, nullptr, 10);
+      if (v >= 1 && v <= fit) waves = static_cast<int>(v);
+    }
+    const size_t lds = smmc::keepdata_lds_bytes(a.table_len, tile, waves);
+    const uint64_t n_wave_chunks = (rest.n_paths + 63) / 64;
+    const uint32_t resident = static_cast<uint32_t>(std::max<size_t>(lds_cu / lds, 1));
+    const uint32_t per_cu = e->keepdata_blocks_per_cu ? e->keepdata_blocks_per_cu : resident;
+    const uint32_t kgrid = static_cast<uint32_t>(
+        std::min<uint64_t>((n_wave_chunks + waves - 1) / waves, static_cast<uint64_t>(e->compute_units) * per_cu));
+    SMMC_HIP(smmc::launch_keepdata(a, exact_div, tile, waves, kgrid, e->stream));
+  }
+  if (comb && d_final) {  // the comb form leaves the final values to a gather of the last column
+    const uint32_t fgrid = static_cast<uint32_t>(std::min<uint64_t>((sim->n_paths + smmc::kBlock - 1) / smmc::kBlock, e->max_grid));
+    SMMC_HIP(smmc::launch_final_column(d_traj, sim->n_paths, static_cast<uint32_t>(row_len), d_final, fgrid, e->stream));
+  }
   return timing_end(e);
 }
 

@@ -68,6 +68,37 @@ __global__ __launch_bounds__(256) void pattern_b(float *out, unsigned long long 
   }
 }
 
+// D: the COMB pattern.  A wave owns 64 streams of K consecutive rows; stream l starts at row
+// super * 2048 + 32 l + w K (w = the wave's slot in its 2048-row super-chunk), so all 64 streams have
+// the same phase modulo a 128-byte line.  Each stream is written window by window (one aligned 128-byte
+// line per visit, 8 streams x 128 B per wave-wide 16-byte store), starting at its first WHOLE line and
+// running through the line in which its last row ends (which holds the head of the next row): every
+// line is written whole, exactly once, no line is shared between two writers.
+__global__ __launch_bounds__(256) void pattern_d(float *out, unsigned long long n_rows, unsigned row_len, unsigned K) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned sub = lane / 8, quad = lane % 8;
+  const unsigned long long base_f = reinterpret_cast<uintptr_t>(out) >> 2;
+  const unsigned waves_per_super = 32 / K;
+  const unsigned long long n_chunks = (n_rows / 2048) * waves_per_super;
+  for (unsigned long long c = (unsigned long long)blockIdx.x * 4 + wave; c < n_chunks; c += (unsigned long long)gridDim.x * 4) {
+    const unsigned long long super = c / waves_per_super;
+    const unsigned w = (unsigned)(c % waves_per_super);
+    const unsigned long long row0 = super * 2048 + (unsigned long long)w * K;  // stream 0's first row
+    const unsigned phi = (unsigned)(base_f + row0 * row_len) & 31u;             // the same for every stream
+    const unsigned first_t = (phi != 0 && row0 != 0) ? 1u : 0u;
+    const unsigned n_t = (phi + K * row_len + 31) / 32;
+    for (unsigned t = first_t; t < n_t; ++t) {
+#pragma unroll
+      for (unsigned it = 0; it < 8; ++it) {
+        const unsigned l = sub + 8 * it;
+        const long long a = (long long)((row0 + 32ull * l) * row_len) - phi + 32ll * t + 4 * quad;
+        if (a >= 0 && (unsigned long long)a + 4 <= n_rows * row_len)
+          *reinterpret_cast<float4 *>(out + a) = make_float4(1.0f + t, 2.0f, 3.0f, 4.0f + l);
+      }
+    }
+  }
+}
+
 int main(int argc, char **argv) {
   const unsigned long long n_rows = 4000000;
   const unsigned row_len = argc > 1 ? atoi(argv[1]) : 361;
@@ -92,6 +123,20 @@ int main(int argc, char **argv) {
       printf("row_len=%u bpc=%d %s: %.3f ms  %.0f GB/s\n", row_len, bpc,
              v == 0 ? "A tile=32 (128 B aligned pieces per row)" : v == 1 ? "A tile=64 (256 B aligned pieces per row)" : "B contiguous per wave", ms,
              bytes / ms / 1e6);
+    }
+  }
+  for (unsigned K : {1u, 2u, 4u, 8u, 16u}) {
+    for (int bpc : {4, 8, 16}) {
+      float ms = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(pattern_d, dim3(256 * bpc), dim3(256), 0, 0, d, n_rows, row_len, K);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      printf("row_len=%u bpc=%d D comb, %u rows per stream (whole lines only): %.3f ms  %.0f GB/s\n", row_len, bpc, K, ms,
+             4.0 * (n_rows / 2048 * 2048) * row_len / ms / 1e6);
     }
   }
   for (int lds_kb : {8, 19, 39, 79}) {     // 160 KiB / lds -> 20(cap 8), 8, 4, 2 workgroups per CU
