@@ -494,7 +494,12 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     const uint32_t per_cu = e->keepdata_blocks_per_cu ? e->keepdata_blocks_per_cu : 1u;
     const uint32_t cgrid = static_cast<uint32_t>(
         std::min<uint64_t>((n_wave_chunks + waves - 1) / waves, static_cast<uint64_t>(e->compute_units) * per_cu));
-    SMMC_HIP(smmc::launch_keepdata_comb(a, exact_div, k_rows, n_wave_chunks, sim->n_paths, waves, cgrid, e->stream));
+    // Philox blocks drawn together per step (instruction-level parallelism at < 4 waves per SIMD)
+    int per_step = (sim->n_periods / draws) % 2u == 0u ? 2 : 1;
+    if (const char *env = std::getenv("SMMC_KEEPDATA_COMB_ILP")) {  // tuning knob
+      if (!std::strcmp(env, "1")) per_step = 1;
+    }
+    SMMC_HIP(smmc::launch_keepdata_comb(a, exact_div, per_step, k_rows, n_wave_chunks, sim->n_paths, waves, cgrid, e->stream));
   }
   if (n_comb < sim->n_paths) {
     smmc_sim rest = *sim;

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Development: counter passes over the keepdata kernel (tools/kd_one.py)
+# Development: counter passes over the keepdata kernels (tools/kd_one.py); environment selects the
+# kernel and mode (SMMC_KEEPDATA_KERNEL, SMMC_KEEPDATA_K, KD_MODE, KD_P, KD_N); TAG names the output.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/kd_pmc
+OUT=$R/gpurun_out/kd_pmc_${TAG:-run}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -13,7 +14,8 @@ while read -r SET; do
 done <<SETS
 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE
-WRITE_SIZE
+WRITE_SIZE GRBM_GUI_ACTIVE
 SETS
 cd $R
-python3 $R/tools/pmc_summary.py $OUT/pass* | grep -A9 "keepdata" 
+python3 $R/tools/pmc_summary.py $OUT/pass* | grep -A10 "keepdata" > $OUT/summary.txt
+cat $OUT/summary.txt
