@@ -98,6 +98,7 @@ struct smmc_engine {
   unsigned long long *d_radix_hist = nullptr;  // kMaxRanks x 2048
   float *d_select_out = nullptr;               // kMaxRanks
   void *d_scratch_stats = nullptr;             // one packed record with SMMC_MAX_BINS buckets
+  unsigned long long *d_work_counter = nullptr;  // the comb keepdata kernel's chunk queue
 
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;  // pairs: start, stop
@@ -387,6 +388,7 @@ void smmc_engine_destroy(smmc_engine *e) {
   if (e->d_radix_hist) (void)hipFree(e->d_radix_hist);
   if (e->d_select_out) (void)hipFree(e->d_select_out);
   if (e->d_scratch_stats) (void)hipFree(e->d_scratch_stats);
+  if (e->d_work_counter) (void)hipFree(e->d_work_counter);
   if (e->d_partials) (void)hipFree(e->d_partials);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -482,8 +484,9 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
       if (v >= 1 && v <= waves) waves = static_cast<int>(v);
     }
     if (waves < 1) return fail(SMMC_ERR_INVALID, "keepdata: the table leaves no LDS for a tile");
-    // rows per stream: 4 (1 % of extra columns at P = 360), fewer while that leaves waves without work
-    uint32_t k_rows = 4;
+    // rows per stream: 1.  More rows cost fewer extra columns (4.3 % at K = 1, 1.1 % at K = 4, P = 360)
+    // but make the chunks a wave takes coarser and its lines sparser in time: K = 1 measured fastest.
+    uint32_t k_rows = 1;
     if (const char *env = std::getenv("SMMC_KEEPDATA_K")) {  // tuning knob: 1, 2, 4, 8, 16 or 32
       const long v = std::strtol(env, nullptr, 10);
       if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k_rows = static_cast<uint32_t>(v);
@@ -499,7 +502,9 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     if (const char *env = std::getenv("SMMC_KEEPDATA_COMB_ILP")) {  // tuning knob
       if (!std::strcmp(env, "1")) per_step = 1;
     }
-    SMMC_HIP(smmc::launch_keepdata_comb(a, exact_div, per_step, k_rows, n_wave_chunks, sim->n_paths, waves, cgrid, e->stream));
+    if (!e->d_work_counter) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_work_counter), sizeof(unsigned long long)));
+    SMMC_HIP(smmc::launch_keepdata_comb(a, exact_div, per_step, k_rows, n_wave_chunks, sim->n_paths, waves, cgrid,
+                                        e->d_work_counter, e->stream));
   }
   if (n_comb < sim->n_paths) {
     smmc_sim rest = *sim;

@@ -83,7 +83,8 @@ hipError_t launch_keepdata(const KernelArgs &a, bool exact_div, int tile, int wa
                            hipStream_t stream);
 // comb form of keepdata (rows [0, 2048 n_super) of a call; see keepdata_comb_kernel)
 hipError_t launch_keepdata_comb(const KernelArgs &a, bool exact_div, int blocks_per_step, uint32_t rows_per_stream,
-                                uint64_t n_wave_chunks, uint64_t n_rows_total, int waves, uint32_t grid, hipStream_t stream);
+                                uint64_t n_wave_chunks, uint64_t n_rows_total, int waves, uint32_t grid,
+                                unsigned long long *next_chunk, hipStream_t stream);
 hipError_t launch_final_column(const float *traj, uint64_t n_rows, uint32_t row_len, float *d_final, uint32_t grid,
                                hipStream_t stream);
 size_t keepdata_comb_lds_bytes(uint32_t table_len, int waves);

@@ -30,8 +30,8 @@ def test_valu_instruction_counts_match_the_built_kernels(asm, mode):
     assert I.valu(chk) - I.valu(c) == pytest.approx(bench.VALU_CHECK_PER_STEP[mode] * periods)
     # one LDS gather per period: a table entry, or (Gaussian) a b128 radius row and a b64 trig pair per two periods
     assert I.lds(c) == periods
-    # the gfx950 forms the loop is built on are really there (two interleaved Philox blocks per trip)
-    assert c["v_bitop3_b32"] >= 2 * 19 and c["v_mad_u64_u32"] >= 2 * 17
+    # the gfx950 forms the loop is built on are really there
+    assert c["v_bitop3_b32"] >= 19 and c["v_mad_u64_u32"] >= 17
 
 
 def test_pmc_traffic_table_names_its_sources():

@@ -19,9 +19,8 @@ W = {'v_pk_fma_f32': 1.9, 'v_pk_mul_f32': 1.9, 'v_pk_add_f32': 1.9, 'v_mad_u64_u
      'v_mul_lo_u32': 1.78, 'v_sqrt_f32_e32': 3.55, 'v_cvt_f32_u32_e32': 1.8, 'v_cvt_f32_i32_e32': 1.8,
      'v_rcp_f32_e32': 3.55, 'v_rsq_f32_e32': 3.55}
 # paths_kernel<mode, div, dense>: (template arguments as mangled, periods per Philox block)
-# (two Philox blocks per trip of the loop: 8 / 16 periods)
-VARIANTS = {"gaussian": ("ILi1ELi0ELb0E", 8), "table": ("ILi0ELi0ELb1E", 16),
-            "gaussian_checked": ("ILi1ELi2ELb0E", 8), "table_checked": ("ILi0ELi2ELb1E", 16)}
+VARIANTS = {"gaussian": ("ILi1ELi0ELb0E", 4), "table": ("ILi0ELi0ELb1E", 8),
+            "gaussian_checked": ("ILi1ELi2ELb0E", 4), "table_checked": ("ILi0ELi2ELb1E", 8)}
 
 
 def emit_asm(out_path, source="smmc_kernels.hip"):
@@ -62,7 +61,7 @@ if __name__ == "__main__":
     else:
         path = emit_asm("/tmp/smmc_kernels.s")
     variant = args[0]
-    periods = int(args[1]) if len(args) > 1 else 8
+    periods = int(args[1]) if len(args) > 1 else 4
     if variant in VARIANTS:
         variant, periods = VARIANTS[variant]
     c = count(path, variant)
