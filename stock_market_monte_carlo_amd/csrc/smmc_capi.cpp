@@ -460,11 +460,29 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   const uint32_t draws = smmc::keepdata_draws(sim->mode == SMMC_MODE_TABLE ? e->table_len : 0u);
   const uint64_t row_len = static_cast<uint64_t>(sim->n_periods) + 1;
   uint64_t n_super = sim->n_paths / 2048u;
-  bool comb = sim->n_periods >= 64u && sim->n_periods % draws == 0u && row_len <= (1u << 20) &&
-              n_super >= static_cast<uint64_t>(e->compute_units) / 2u;
+  const bool comb_fits = sim->n_periods >= 64u && sim->n_periods % draws == 0u && row_len <= (1u << 20) && n_super >= 1;
+  // waves per workgroup of the comb form: what fits the CU's LDS beside the tables, one workgroup per
+  // CU; table mode (tiles of 40 columns: 14 would fit) runs 12, three per SIMD: 3 % faster than 14
+  int comb_waves = 0;
+  if (comb_fits) {
+    const size_t lds_cu = 160u * 1024u;
+    const uint32_t tl = sim->mode == SMMC_MODE_TABLE ? e->table_len : 0u;
+    const size_t fixed = smmc::keepdata_comb_lds_bytes(tl, 0);
+    const size_t per_wave = smmc::keepdata_comb_lds_bytes(tl, 1) - fixed;
+    comb_waves = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 16)) : 0;
+    if (sim->mode == SMMC_MODE_TABLE && comb_waves > 12) comb_waves = 12;
+    if (const char *env = std::getenv("SMMC_KEEPDATA_COMB_WAVES")) {  // tuning knob
+      const long v = std::strtol(env, nullptr, 10);
+      if (v >= 1 && v <= comb_waves) comb_waves = static_cast<int>(v);
+    }
+  }
+  // the comb form needs enough chunks (64 rows each) to keep its waves level: below ~8 per wave
+  // (2e6 rows) the tile kernel's finer grain wins (0.20 vs 0.26 ms at 6e5 rows of 361 values)
+  bool comb = comb_fits && comb_waves >= 1 &&
+              n_super * 32u >= 8ull * e->compute_units * static_cast<uint64_t>(comb_waves);
   if (const char *env = std::getenv("SMMC_KEEPDATA_KERNEL")) {
     if (!std::strcmp(env, "tile")) comb = false;
-    if (!std::strcmp(env, "comb")) comb = sim->n_periods >= 64u && sim->n_periods % draws == 0u && row_len <= (1u << 20) && n_super >= 1;
+    if (!std::strcmp(env, "comb")) comb = comb_fits && comb_waves >= 1;
   }
   const uint64_t n_comb = comb ? n_super * 2048u : 0u;
   rc = timing_begin(e);
@@ -474,16 +492,7 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     a.d_traj = d_traj;
     a.d_final = nullptr;
     a.n_paths = n_comb;
-    // waves per workgroup: what fits the CU's LDS beside the tables, one workgroup per CU
-    const size_t lds_cu = 160u * 1024u;
-    const size_t fixed = smmc::keepdata_comb_lds_bytes(a.table_len, 0);
-    const size_t per_wave = smmc::keepdata_comb_lds_bytes(a.table_len, 1) - fixed;
-    int waves = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 16)) : 0;
-    if (const char *env = std::getenv("SMMC_KEEPDATA_COMB_WAVES")) {  // tuning knob
-      const long v = std::strtol(env, nullptr, 10);
-      if (v >= 1 && v <= waves) waves = static_cast<int>(v);
-    }
-    if (waves < 1) return fail(SMMC_ERR_INVALID, "keepdata: the table leaves no LDS for a tile");
+    const int waves = comb_waves;
     // rows per stream: 1.  More rows cost fewer extra columns (4.3 % at K = 1, 1.1 % at K = 4, P = 360)
     // but make the chunks a wave takes coarser and its lines sparser in time: K = 1 measured fastest.
     uint32_t k_rows = 1;

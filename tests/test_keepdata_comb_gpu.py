@@ -106,7 +106,7 @@ def test_comb_is_chosen_for_large_calls_and_equals_the_tile_kernel(eng, table, m
     final values equal the last column and the paths kernel's."""
     import torch
     import stock_market_monte_carlo_amd as S
-    n, p = 600_000 + 1234, 360
+    n, p = 2_000_000 + 1234, 360  # above the selection threshold (8 chunks of 64 rows per wave)
     for mode in (S.MODE_TABLE, S.MODE_GAUSSIAN):
         sim = S.Engine.make_sim(n, p, mode, SEED, first_path=7)
         monkeypatch.delenv("SMMC_KEEPDATA_KERNEL", raising=False)
