@@ -493,9 +493,11 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     a.d_final = nullptr;
     a.n_paths = n_comb;
     const int waves = comb_waves;
-    // rows per stream: 1.  More rows cost fewer extra columns (4.3 % at K = 1, 1.1 % at K = 4, P = 360)
-    // but make the chunks a wave takes coarser and its lines sparser in time: K = 1 measured fastest.
-    uint32_t k_rows = 1;
+    // rows per stream.  More rows cost fewer extra columns (4.3 % at K = 1, 2.1 % at K = 2, 1.1 % at
+    // K = 4 for P = 360) but make the chunks a wave takes coarser.  Measured (tools/kd_ab.py, 4e6 x 361):
+    // Gaussian, where the columns cost arithmetic, K = 2 (1.300 ms; K = 1 1.318, K = 4 1.45);
+    // table mode, bound by the stores, K = 1 (1.106 ms; K = 2 1.124).
+    uint32_t k_rows = sim->mode == SMMC_MODE_GAUSSIAN ? 2 : 1;
     if (const char *env = std::getenv("SMMC_KEEPDATA_K")) {  // tuning knob: 1, 2, 4, 8, 16 or 32
       const long v = std::strtol(env, nullptr, 10);
       if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k_rows = static_cast<uint32_t>(v);
