@@ -476,10 +476,11 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
       if (v >= 1 && v <= comb_waves) comb_waves = static_cast<int>(v);
     }
   }
-  // the comb form needs enough chunks (64 rows each) to keep its waves level: below ~8 per wave
-  // (2e6 rows) the tile kernel's finer grain wins (0.20 vs 0.26 ms at 6e5 rows of 361 values)
+  // the comb form needs enough chunks (64 rows each) to keep its waves level: below ~4 per wave
+  // (1e6 rows) the tile kernel's finer grain wins (0.20 vs 0.26 ms at 6e5 rows of 361 values; at
+  // 1.5e6 rows of 1001 values the comb form is ahead, 1.41 vs 1.58 ms in Gaussian mode)
   bool comb = comb_fits && comb_waves >= 1 &&
-              n_super * 32u >= 8ull * e->compute_units * static_cast<uint64_t>(comb_waves);
+              n_super * 32u >= 4ull * e->compute_units * static_cast<uint64_t>(comb_waves);
   if (const char *env = std::getenv("SMMC_KEEPDATA_KERNEL")) {
     if (!std::strcmp(env, "tile")) comb = false;
     if (!std::strcmp(env, "comb")) comb = comb_fits && comb_waves >= 1;
