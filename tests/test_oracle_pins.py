@@ -102,3 +102,22 @@ def test_many_updates_shape_and_chain(oracle):
         t = (t * (np.float32(100.0) + r)) / np.float32(100.0)
         assert _bits(float(out[i + 1])) == _bits(float(t))
     assert oracle.many_updates(5.0, rets, 0).tolist() == [5.0]
+
+
+def test_engine_R_equals_the_reference_loop_written_with_the_real_libstdcxx_classes(oracle, table):
+    """oracle/asref_cpu.cpp is the reference's per-path loop (src/simulations.cpp:240-252) with
+    std::mt19937 + std::uniform_int_distribution<int> themselves; seeded with seed0 + id instead of
+    std::random_device it must give engine (R)'s bits -- the hand-written mt19937 and Lemire map checked
+    against the library on whole paths, ragged block counts and thread counts."""
+    for n, p, seed0, threads in ((2501, 37, 777, 2), (1000, 360, 0xFFFFFFF0, 3), (17, 1000, 5489, 1), (5, 0, 1, 1)):
+        a, _ = oracle.asref_mc_simulations(n, p, 1000.0, table, n_threads=threads, fixed_seed0=seed0)
+        b, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0, n_threads=threads)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n, p, seed0)
+    # unseeded (the reference's behaviour): not reproducible, but the same distribution
+    a, used = oracle.asref_mc_simulations(20000, 120, 1000.0, table, n_threads=2)
+    b, _ = oracle.asref_mc_simulations(20000, 120, 1000.0, table, n_threads=2)
+    assert used == 2 and not np.array_equal(a, b)
+    r, _ = oracle.ref_mc_simulations(20000, 120, 1000.0, table, 1, n_threads=2)
+    la, lr = np.log(a.astype(np.float64) / 1000.0), np.log(r.astype(np.float64) / 1000.0)
+    se = lr.std() / np.sqrt(lr.size) * np.sqrt(2.0)
+    assert abs(la.mean() - lr.mean()) < 5 * se and abs(la.std() / lr.std() - 1.0) < 0.05
