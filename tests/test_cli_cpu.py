@@ -47,3 +47,24 @@ def test_dropin_header_is_self_contained(tmp_path):
                    "void (*h)(std::atomic<long>&,long,unsigned int,float,std::vector<float>&,std::vector<float>&) = &mc_simulations; (void)h; "
                    "return 0;}\n")
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)])
+
+
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "benchmark_mc_gpu")),
+                    reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_reference_gpu_main_starts_with_the_aliased_locale():
+    """The reference's own benchmark_mc_gpu main, compiled untouched: without LOCPATH it dies in
+    std::locale("en_US.UTF-8"); with the image's C.utf8 offered under that name it reaches the drop-in
+    library (which, without a GPU, refuses loudly)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(REF_DIR, "benchmark_mc_gpu")
+    env = {k: v for k, v in os.environ.items() if k != "LOCPATH"}
+    r = subprocess.run([exe, "1", "360", "1000"], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "locale" in r.stderr
+    r = subprocess.run([exe, "1", "360", "1000"], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(env, LOCPATH=os.path.join(REF_DIR, "locale")))
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr and "locale" not in r.stderr

@@ -155,8 +155,7 @@ REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 def test_reference_programs_compiled_unmodified_run_on_the_drop_in():
     """examples/benchmark_mc_cpu_v2.cpp and examples/benchmark_mc_cpu.cpp of the reference, compiled
     from its own sources (oracle/Makefile target _ref) against this header and library: the
-    drop-in claim at link level.  (benchmark_mc_gpu*.cpp call std::locale("en_US.UTF-8"), which
-    this image does not have, so they cannot start here with any backend.)"""
+    drop-in claim at link level."""
     env = dict(os.environ, SMMC_SEED="7")
     r = subprocess.run([os.path.join(REF_DIR, "benchmark_mc_cpu_v2"), "360", "2000000"], cwd=ROOT, env=env,
                        capture_output=True, text=True)
@@ -167,3 +166,38 @@ def test_reference_programs_compiled_unmodified_run_on_the_drop_in():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert re.search(r"All 100000 simulation done in [0-9.e+-]+ s!", r.stdout)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "benchmark_mc_gpu")),
+                    reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_reference_gpu_programs_compiled_unmodified_run_on_the_drop_in(oracle, table):
+    """examples/benchmark_mc_gpu.cpp and examples/benchmark_mc_gpu_reduceBlock.cpp of the reference,
+    compiled untouched.  Their mains ask for the en_US.UTF-8 locale (benchmark_mc_gpu.cpp:45), which the
+    image lacks: LOCPATH offers the image's own C.utf8 locale under that name (oracle/Makefile), nothing
+    else changes.  The numbers they print must be the oracle's."""
+    env = dict(os.environ, SMMC_SEED="99", LOCPATH=os.path.join(REF_DIR, "locale"))
+    n = 200000
+    r = subprocess.run([os.path.join(REF_DIR, "benchmark_mc_gpu"), "1", "360", str(n)], cwd=ROOT, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert f"n_periods: 360 | max_n_simulations: {n}" in r.stdout
+    assert re.search(rf"All {n} simulation done in [0-9.e+-]+ s!", r.stdout)
+    want = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 360, n, 99, table=table))["final"]
+    m = re.search(r"mean: ([0-9.]+) \| std: ([0-9.]+)", r.stdout)
+    c = re.search(r"count_below 1000.0: ([0-9,]+) \(", r.stdout)
+    w64 = want.astype(np.float64)
+    assert float(m.group(1)) == pytest.approx(w64.mean(), abs=0.006)
+    assert float(m.group(2)) == pytest.approx(w64.std(), rel=1e-4)
+    assert int(c.group(1).replace(",", "")) == int((want < 1000.0).sum())
+    # three shards through the reference's own main (its n_gpus is argv[1]), all on this box's GPU
+    r3 = subprocess.run([os.path.join(REF_DIR, "benchmark_mc_gpu"), "3", "360", str(n)], cwd=ROOT,
+                        env=dict(env, SMMC_DEVICE_MAP="0,0,0"), capture_output=True, text=True)
+    assert r3.returncode == 0, r3.stderr
+    assert re.search(r"mean: [0-9.]+ \| std: [0-9.]+", r3.stdout).group(0) == m.group(0)
+    # the block-reduce program: per-block means merged its own way (examples/benchmark_mc_gpu_reduceBlock.cpp:7-26)
+    rb = subprocess.run([os.path.join(REF_DIR, "benchmark_mc_gpu_reduceBlock"), "1", "360", str(n)], cwd=ROOT, env=env,
+                        capture_output=True, text=True)
+    assert rb.returncode == 0, rb.stderr
+    mb = re.search(r"mean: ([0-9.]+) \| std: ([0-9.]+)", rb.stdout)
+    cm, _ = oracle.chunk_mean_var(want)
+    assert float(mb.group(1)) == pytest.approx(float(cm.astype(np.float64).mean()), rel=1e-4)
