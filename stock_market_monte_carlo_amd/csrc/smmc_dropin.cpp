@@ -258,10 +258,9 @@ void warm_engines(long n_total, int n_gpus, const std::vector<float> *table) {
   for_each_shard(n_total, n_gpus, [&](const Shard &sh) { Session ses(sh.device, table, sh.lane); });
 }
 
-// The callee-sized result of mc_simulations_gpu (src/simulations.cu:643-644).  The engines come up
-// first and the vector is sized after, not beside them: with both at once the HIP runtime's start-up
-// (which maps memory) and the page population fight over the process's mmap lock (engines 35 ms alone,
-// 190-250 ms beside the population).
+// The callee-sized result of mc_simulations_gpu (src/simulations.cu:643-644): engines first (in a fresh
+// process that is the HIP runtime's start-up, 190-240 ms, tools/ubench_startup.cpp), then the vector
+// (17-20 ms).  Sizing it on a helper thread beside the start-up was tried and saved nothing measurable.
 void size_result_and_warm(std::vector<float> &totals, long n_total, int n_gpus, const std::vector<float> *table) {
   const auto t0 = std::chrono::steady_clock::now();
   warm_engines(n_total, n_gpus, table);
