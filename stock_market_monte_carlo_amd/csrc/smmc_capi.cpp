@@ -99,6 +99,7 @@ struct smmc_engine {
   float *d_select_out = nullptr;               // kMaxRanks
   void *d_scratch_stats = nullptr;             // one packed record with SMMC_MAX_BINS buckets
   unsigned long long *d_work_counter = nullptr;  // the comb keepdata kernel's chunk queue
+  unsigned long long *d_hist_spread = nullptr;   // values_stats: kHistSpread copies of the bucket array
 
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;  // pairs: start, stop
@@ -389,6 +390,7 @@ void smmc_engine_destroy(smmc_engine *e) {
   if (e->d_select_out) (void)hipFree(e->d_select_out);
   if (e->d_scratch_stats) (void)hipFree(e->d_scratch_stats);
   if (e->d_work_counter) (void)hipFree(e->d_work_counter);
+  if (e->d_hist_spread) (void)hipFree(e->d_hist_spread);
   if (e->d_partials) (void)hipFree(e->d_partials);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -807,6 +809,13 @@ int smmc_engine_values_stats(smmc_engine *e, const float *d_values, uint64_t n, 
   a.hist_inv = n_bins ? static_cast<double>(n_bins) / (static_cast<double>(hist_hi) - static_cast<double>(hist_lo)) : 0.0;
   a.partials = e->d_partials;
   a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
+  if (n_bins && n) {  // spread copies of the bucket array (see ValuesArgs)
+    if (!e->d_hist_spread)
+      SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_hist_spread), sizeof(unsigned long long) * smmc::kHistSpread * SMMC_MAX_BINS));
+    SMMC_HIP(hipMemsetAsync(e->d_hist_spread, 0, sizeof(unsigned long long) * smmc::kHistSpread * n_bins, e->stream));
+    a.hist_spread = e->d_hist_spread;
+    a.spread = smmc::kHistSpread;
+  }
   // 16 bytes per lane per iteration; enough workgroups to keep every CU's memory pipe full
   const uint64_t want = (n / 4 + smmc::kBlock - 1) / smmc::kBlock;
   uint32_t per_cu = 8;  // 8 x 4 waves: every workgroup resident at once, one round
@@ -822,7 +831,8 @@ int smmc_engine_values_stats(smmc_engine *e, const float *d_values, uint64_t n, 
     rc = timing_end(e);
     if (rc) return rc;
   }
-  SMMC_HIP(smmc::launch_finalize(e->d_partials, n ? grid : 0u, static_cast<smmc_stats *>(d_stats), n_bins, e->stream));
+  SMMC_HIP(smmc::launch_finalize(e->d_partials, n ? grid : 0u, static_cast<smmc_stats *>(d_stats), n_bins, e->stream,
+                                 a.hist_spread, a.spread));
   return SMMC_OK;
 }
 

@@ -51,8 +51,14 @@ struct ValuesArgs {
   double hist_inv;
   BlockPartial *partials;
   unsigned long long *d_hist;
+  // values_stats: every workgroup is resident for the whole launch and flushes its histogram at the
+  // same moment; `spread` zeroed copies of the bucket array (workgroup b adds to copy b % spread) cut
+  // the adds that queue on one address from 2048 to 128; finalize_kernel folds the copies
+  unsigned long long *hist_spread;
+  uint32_t spread;
 };
 uint32_t values_hist_copies(uint32_t n_bins);
+constexpr uint32_t kHistSpread = 16;
 
 // radix selection state: per requested rank, the key bits fixed so far and the rank
 // relative to the values that share those bits
@@ -78,7 +84,8 @@ hipError_t launch_radix_pick(int pass, uint32_t n_ranks, SelectState *st, const 
 hipError_t launch_paths(const KernelArgs &a, int div, uint32_t grid, size_t lds_bytes,
                         hipStream_t stream);
 hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, smmc_stats *d_stats,
-                           uint32_t n_bins, hipStream_t stream);
+                           uint32_t n_bins, hipStream_t stream, const unsigned long long *hist_spread = nullptr,
+                           uint32_t spread = 0);
 hipError_t launch_keepdata(const KernelArgs &a, bool exact_div, int tile, int waves, uint32_t grid,
                            hipStream_t stream);
 // comb form of keepdata (rows [0, 2048 n_super) of a call; see keepdata_comb_kernel)

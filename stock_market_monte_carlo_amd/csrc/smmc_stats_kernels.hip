@@ -153,7 +153,8 @@ __global__ __launch_bounds__(kBlock) void values_stats_kernel(const ValuesArgs k
     for (uint32_t b = tid; b < k.n_bins; b += kBlock) {
       uint32_t c = 0;
       for (uint32_t r = 0; r < k.hist_copies; ++r) c += lds_all[r * stride + b];
-      if (c) atomicAdd(&k.d_hist[b], static_cast<unsigned long long>(c));
+      unsigned long long *dst = k.spread ? k.hist_spread + static_cast<size_t>(blockIdx.x % k.spread) * k.n_bins : k.d_hist;
+      if (c) atomicAdd(&dst[b], static_cast<unsigned long long>(c));
     }
   }
 }
