@@ -12,6 +12,11 @@ hipError_t launch_radix_pick(int, uint32_t, SelectState *, const unsigned long l
 hipError_t launch_paths(const KernelArgs &, int, uint32_t, size_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_finalize(const BlockPartial *, uint32_t, smmc_stats *, uint32_t, hipStream_t, const unsigned long long *, uint32_t) { return hipErrorNoDevice; }
 hipError_t launch_keepdata(const KernelArgs &, bool, int, int, uint32_t, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_keepdata_comb(const KernelArgs &, bool, int, uint32_t, uint64_t, uint64_t, int, uint32_t, unsigned long long *,
+                                hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_final_column(const float *, uint64_t, uint32_t, float *, uint32_t, hipStream_t) { return hipErrorNoDevice; }
+size_t keepdata_comb_lds_bytes(uint32_t, int) { return 0; }
+uint32_t keepdata_draws(uint32_t table_len) { return (table_len && table_len <= 2048u) ? 8u : 4u; }
 hipError_t launch_selftest(uint32_t, uint32_t, unsigned long long *, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 uint32_t values_hist_copies(uint32_t) { return 1; }
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins) { return (static_cast<size_t>(table_len) + n_bins) * 4u; }
