@@ -39,7 +39,6 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-constexpr int kWaves = kBlock / 64;
 
 // Streams the float4 body of an array through f, grid-wide: two ADJACENT 16-byte loads in flight
 // per lane (a wave reads 2 KiB contiguous).  Measured on 1e9 values against the alternatives
@@ -91,21 +90,27 @@ __device__ __forceinline__ void take(Acc &a, float v, const ValuesArgs &k, uint3
 }
 
 // One pass over n floats: 16-byte loads on the aligned body, scalar head and tail.
+// 1024-thread workgroups, two per CU: every workgroup is resident for the whole launch and flushes
+// its histogram at the same moment at the end, so the number of workgroups sets the length of that
+// tail (2048 workgroups of 256 threads: 0.099 ms for 1e8 values; spread over 16 bucket arrays: 0.086;
+// 512 of 1024 threads: see DESIGN.md section 5).
+constexpr int kStatsBlock = 1024;
+constexpr int kStatsWaves = kStatsBlock / 64;
 template <bool kHist>
-__global__ __launch_bounds__(kBlock) void values_stats_kernel(const ValuesArgs k) {
+__global__ __launch_bounds__(kStatsBlock) void values_stats_kernel(const ValuesArgs k) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t *lds_all = reinterpret_cast<uint32_t *>(lds_raw);
-  __shared__ BlockPartial wave_part[kWaves];
+  __shared__ BlockPartial wave_part[kStatsWaves];
   const uint32_t tid = threadIdx.x;
   const uint32_t stride = hist_stride(k.n_bins);
   uint32_t *lds_hist = lds_all + (tid % k.hist_copies) * stride;  // this lane's copy
   if constexpr (kHist) {
-    for (uint32_t i = tid; i < k.hist_copies * stride; i += kBlock) lds_all[i] = 0u;
+    for (uint32_t i = tid; i < k.hist_copies * stride; i += kStatsBlock) lds_all[i] = 0u;
     __syncthreads();
   }
   Acc a;
-  const uint64_t gtid = static_cast<uint64_t>(blockIdx.x) * kBlock + tid;
-  const uint64_t gsize = static_cast<uint64_t>(gridDim.x) * kBlock;
+  const uint64_t gtid = static_cast<uint64_t>(blockIdx.x) * kStatsBlock + tid;
+  const uint64_t gsize = static_cast<uint64_t>(gridDim.x) * kStatsBlock;
   // head: elements before the first 16-byte boundary
   const uint64_t mis = (reinterpret_cast<uintptr_t>(k.values) >> 2) & 3u;
   uint64_t head = mis ? 4 - mis : 0;
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void values_stats_kernel(const ValuesArgs k
   if (tid == 0) {
     BlockPartial t = wave_part[0];
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) {
+    for (int w = 1; w < kStatsWaves; ++w) {
       t.sum += wave_part[w].sum;
       t.sumsq += wave_part[w].sumsq;
       t.count += wave_part[w].count;
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void values_stats_kernel(const ValuesArgs k
     k.partials[blockIdx.x] = t;
   }
   if constexpr (kHist) {  // the barrier above also closed the LDS atomics
-    for (uint32_t b = tid; b < k.n_bins; b += kBlock) {
+    for (uint32_t b = tid; b < k.n_bins; b += kStatsBlock) {
       uint32_t c = 0;
       for (uint32_t r = 0; r < k.hist_copies; ++r) c += lds_all[r * stride + b];
       unsigned long long *dst = k.spread ? k.hist_spread + static_cast<size_t>(blockIdx.x % k.spread) * k.n_bins : k.d_hist;
@@ -299,10 +304,10 @@ uint32_t values_hist_copies(uint32_t n_bins) {
 
 hipError_t launch_values_stats(const ValuesArgs &a, uint32_t grid, hipStream_t stream) {
   if (a.n_bins)
-    hipLaunchKernelGGL((values_stats_kernel<true>), dim3(grid), dim3(kBlock),
+    hipLaunchKernelGGL((values_stats_kernel<true>), dim3(grid), dim3(kStatsBlock),
                        a.hist_copies * (a.n_bins | 1u) * 4u, stream, a);
   else
-    hipLaunchKernelGGL((values_stats_kernel<false>), dim3(grid), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((values_stats_kernel<false>), dim3(grid), dim3(kStatsBlock), 0, stream, a);
   return hipGetLastError();
 }
 
