@@ -32,6 +32,7 @@ class Params(C.Structure):
         ("hist_lo", C.c_float),
         ("hist_hi", C.c_float),
         ("below_threshold", C.c_float),
+        ("stream", C.c_uint32),
     ]
 
 
@@ -69,6 +70,10 @@ def lib():
         L.orc_bm_radius.argtypes = [C.c_uint32]
         L.orc_bm_radius_scan.restype = C.c_double
         L.orc_bm_radius_scan.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.orc_bm3_radius.restype = C.c_float
+        L.orc_bm3_radius.argtypes = [C.c_uint32]
+        L.orc_bm3_radius_scan.restype = C.c_double
+        L.orc_bm3_radius_scan.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_hist_bucket.restype = C.c_int32
         L.orc_hist_bucket.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32]
         L.orc_div100_mismatches.restype = C.c_uint64
@@ -146,6 +151,29 @@ def box_muller(ua, ub):
     return a.value, b.value
 
 
+def box_muller3(ua, ub):
+    """Counter stream v3's standard normals of (ua, ub)."""
+    a = C.c_float()
+    b = C.c_float()
+    lib().orc_box_muller3(C.c_uint32(ua), C.c_uint32(ub), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def box_muller3_scaled(ua, ub, scale, shift):
+    a = C.c_float()
+    b = C.c_float()
+    lib().orc_box_muller3_scaled(C.c_uint32(ua), C.c_uint32(ub), C.c_float(scale), C.c_float(shift), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def bm3_radius(ua):
+    return float(lib().orc_bm3_radius(C.c_uint32(ua)))
+
+
+def bm3_radius_scan(lo, hi, stride):
+    return float(lib().orc_bm3_radius_scan(C.c_uint64(lo), C.c_uint64(hi), C.c_uint64(stride)))
+
+
 def ref_mc_simulations(n_paths, n_periods, initial_capital, table, seed0, n_threads=0):
     """Engine (R): returns (final_values, threads_used)."""
     t = _f32(table)
@@ -186,7 +214,7 @@ def asref_mc_simulations(n_paths, n_periods, initial_capital, table, n_threads=0
 
 def make_params(mode, n_periods, n_paths, seed, first_path=0, initial_capital=1000.0, table=None,
                 gauss_mean=0.5, gauss_std=0.83333, n_bins=0, hist_lo=0.0, hist_hi=1.0,
-                below_threshold=1000.0):
+                below_threshold=1000.0, stream=3):
     p = Params()
     p.mode = mode
     p.n_periods = n_periods
@@ -205,6 +233,7 @@ def make_params(mode, n_periods, n_paths, seed, first_path=0, initial_capital=10
     p.hist_lo = hist_lo
     p.hist_hi = hist_hi
     p.below_threshold = below_threshold
+    p.stream = stream
     p._keep = keep
     return p
 

@@ -252,6 +252,60 @@ ORC_API void orc_box_muller(uint32_t ua, uint32_t ub, float *z_cos, float *z_sin
   orc_box_muller_scaled(ua, ub, 1.0f, 0.0f, z_cos, z_sin);
 }
 
+/* ---- counter stream v3: the same construction with cheaper index arithmetic -------------------
+ * (round 2: the Gaussian path step is bound by VALU instruction count; v3 needs 26 instead of 30.5
+ * per period on the device.  Table mode is the same in v2 and v3.)
+ * Radius: w = ua ^ (ua >>a 31) as before, f = (float)(w | 1) (one three-input bit operation on the
+ * device), u = f / 2^32 in (0, 1/2]: exponent 127 .. 158, 32 octaves x 16 sub-intervals per side,
+ * stored rotated so that the table index is ONE bit-field: (bits >> 19) & 511, side at +512.  The
+ * cubic's argument is x' = as_float(0x3f800000 | low 19 mantissa bits) - (1 + 1/32), in
+ * [-1/32, 1/32): no shift (the coefficients carry the factor 16^k).  Tail: u >= 2^-32, 6.66 sigma. */
+ORC_API float orc_bm3_radius(uint32_t ua) {
+  uint32_t mask = (uint32_t)((int32_t)ua >> 31);
+  uint32_t w1 = (ua ^ mask) | 1u;               /* odd, in [1, 2^31) */
+  uint32_t bits = f2u((float)w1);               /* round to nearest even, exponent 127 .. 158 */
+  uint32_t entry = ((bits >> 19) & 511u) | (mask & 512u);
+  float x = u2f(0x3f800000u | (bits & 0x0007ffffu)) - 1.03125f; /* exact */
+  const float *k = smmc_bm3_radius[entry];
+  return fmaf(fmaf(fmaf(k[3], x, k[2]), x, k[1]), x, k[0]);
+}
+
+/* Angle: 512-entry table, theta = 2 pi i / 512 + delta, i = (ub + 2^22) >> 23 (mod 512),
+ * delta = sext23(ub) * 2 pi / 2^32, |delta| <= pi/512 = 6.1e-3: sin(delta) = delta (error
+ * delta^3/6 <= 3.9e-8), cos(delta) = 1 - delta^2/2 (error 6e-11).  |dz| < 1.1e-6 vs double for
+ * scale = 1 (tests/test_numerics_cpu.py). */
+ORC_API void orc_box_muller3_scaled(uint32_t ua, uint32_t ub, float scale, float shift, float *d_cos, float *d_sin) {
+  float rs = orc_bm3_radius(ua) * scale;
+  uint32_t i = (ub + 0x00400000u) >> 23;
+  int32_t d = (int32_t)(ub << 9) >> 9; /* low 23 bits, sign-extended */
+  float delta = (float)d * 0x1.921fb6p-30f;
+  float cd = fmaf(delta * delta, -0.5f, 1.0f);
+  float ci = smmc_bm3_trig[i][0], si = smmc_bm3_trig[i][1];
+  float ct = fmaf(-si, delta, ci * cd);
+  float st = fmaf(ci, delta, si * cd);
+  *d_cos = fmaf(rs, ct, shift);
+  *d_sin = fmaf(rs, st, shift);
+}
+
+ORC_API void orc_box_muller3(uint32_t ua, uint32_t ub, float *z_cos, float *z_sin) {
+  orc_box_muller3_scaled(ua, ub, 1.0f, 0.0f, z_cos, z_sin);
+}
+
+/* max |r - sqrt(-2 ln u)| over ua = lo, lo + stride, ... < hi (v3 radius against double) */
+ORC_API double orc_bm3_radius_scan(uint64_t lo, uint64_t hi, uint64_t stride) {
+  double worst = 0.0;
+  for (uint64_t a = lo; a < hi; a += stride) {
+    uint32_t ua = (uint32_t)a;
+    uint32_t mask = (uint32_t)((int32_t)ua >> 31);
+    uint32_t w1 = (ua ^ mask) | 1u;
+    double u = (double)(float)w1 / 4294967296.0;
+    double want = mask ? sqrt(-2.0 * log1p(-u)) : sqrt(-2.0 * log(u));
+    double e = fabs((double)orc_bm3_radius(ua) - want);
+    if (e > worst) worst = e;
+  }
+  return worst;
+}
+
 typedef struct {
   int32_t mode;          /* ORC_MODE_* */
   uint32_t n_periods;
@@ -266,6 +320,7 @@ typedef struct {
   uint32_t n_bins;       /* 0 = no histogram */
   float hist_lo, hist_hi;
   float below_threshold;
+  uint32_t stream;       /* Gaussian draw: 2 = counter stream v2, anything else (0, 3) = v3 */
 } orc_params;
 
 typedef struct {
@@ -301,18 +356,22 @@ static void digits4(uint32_t h, uint32_t l, uint32_t T, uint32_t idx[4]) {
   idx[3] = (uint32_t)(((uint64_t)h * T) >> 32);
 }
 
-/* The draws of Philox block `blk` of one path, in percent (table mode: the table
- * entry; Gaussian mode: fma(std, z, mean)): orc_draws_per_block() values.  Period p
- * uses draw p % D of block p / D. */
+/* The draws of Philox block `blk` of one path: orc_draws_per_block() of them.  out[] are the period
+ * returns in percent, mult[] the multipliers a = 100 + return the compounding step uses (period p
+ * uses draw p % D of block p / D).  Table mode and Gaussian v2: the return is drawn (table entry;
+ * fma(std, z, mean)) and a = 100.0f + return.  Gaussian v3: the MULTIPLIER is drawn,
+ * a = fma(r std, cos theta, 100.0f + mean), and the return is defined as a - 100.0f (exact for
+ * a in [50, 200], where update_fund(total, return) then reproduces total * a / 100 bit for bit). */
 static void path_returns_block(const orc_params *p, uint64_t path, uint32_t blk, float out[8],
-                               uint32_t idx_out[8]) {
+                               uint32_t idx_out[8], float mult[8]) {
   uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), blk, (uint32_t)p->mode};
   uint32_t key[2] = {(uint32_t)p->seed, (uint32_t)(p->seed >> 32)};
   uint32_t u[4];
+  float a[8];
+  uint32_t n = orc_draws_per_block(p->mode, p->table_len);
   orc_philox4x32_10(ctr, key, u);
   if (p->mode == ORC_MODE_TABLE) {
     uint32_t idx[8];
-    uint32_t n = orc_draws_per_block(p->mode, p->table_len);
     if (n == 8) {
       digits4(u[0], u[1], p->table_len, idx);
       digits4(u[2], u[3], p->table_len, idx + 4);
@@ -322,11 +381,20 @@ static void path_returns_block(const orc_params *p, uint64_t path, uint32_t blk,
     for (uint32_t j = 0; j < n; j++) {
       if (idx_out) idx_out[j] = idx[j];
       out[j] = p->table[idx[j]];
+      a[j] = 100.0f + out[j];
     }
-  } else {
+  } else if (p->stream == 2) {
     orc_box_muller_scaled(u[0], u[1], p->gauss_std, p->gauss_mean, &out[0], &out[1]);
     orc_box_muller_scaled(u[2], u[3], p->gauss_std, p->gauss_mean, &out[2], &out[3]);
+    for (int j = 0; j < 4; j++) a[j] = 100.0f + out[j];
+  } else {
+    const float shift = 100.0f + p->gauss_mean;
+    orc_box_muller3_scaled(u[0], u[1], p->gauss_std, shift, &a[0], &a[1]);
+    orc_box_muller3_scaled(u[2], u[3], p->gauss_std, shift, &a[2], &a[3]);
+    for (int j = 0; j < 4; j++) out[j] = a[j] - 100.0f;
   }
+  if (mult)
+    for (uint32_t j = 0; j < n; j++) mult[j] = a[j];
 }
 
 /* Writes the n_periods returns of global path `path` (percent). */
@@ -334,7 +402,7 @@ ORC_API void orc_counter_path_returns(const orc_params *p, uint64_t path, float 
   const uint32_t D = orc_draws_per_block(p->mode, p->table_len);
   for (uint32_t i = 0; i < p->n_periods; i += D) {
     float r[8];
-    path_returns_block(p, path, i / D, r, 0);
+    path_returns_block(p, path, i / D, r, 0, 0);
     for (uint32_t j = 0; j < D && i + j < p->n_periods; j++) returns[i + j] = r[j];
   }
 }
@@ -345,7 +413,7 @@ ORC_API void orc_counter_path_indices(const orc_params *p, uint64_t path, uint32
   for (uint32_t i = 0; i < p->n_periods; i += D) {
     float r[8];
     uint32_t idx[8];
-    path_returns_block(p, path, i / D, r, idx);
+    path_returns_block(p, path, i / D, r, idx, 0);
     for (uint32_t j = 0; j < D && i + j < p->n_periods; j++) indices[i + j] = idx[j];
   }
 }
@@ -355,10 +423,12 @@ static float counter_one_path(const orc_params *p, uint64_t path, float *traject
   float total = p->initial_capital;
   if (trajectory) trajectory[0] = total;
   for (uint32_t i = 0; i < p->n_periods; i += D) {
-    float r[8];
-    path_returns_block(p, path, i / D, r, 0);
+    float r[8], a[8];
+    path_returns_block(p, path, i / D, r, 0, a);
     for (uint32_t j = 0; j < D && i + j < p->n_periods; j++) {
-      total = orc_update_fund(total, r[j]);
+      /* update_fund (src/simulations.cpp:14-16) from its second rounding on: a = 100.0f + r is formed above */
+      const float m = total * a[j];
+      total = m / 100.0f;
       if (trajectory) trajectory[i + j + 1] = total;
     }
   }

@@ -19,6 +19,7 @@ ABI_VERSION = 2
 MODE_TABLE = 0
 MODE_GAUSSIAN = 1
 FLAG_EXACT_DIV = 1
+FLAG_STREAM_V2 = 2  # Gaussian draws of counter stream v2 instead of v3
 CHUNK = 256
 MAX_TABLE = 16384
 MAX_BINS = 4096

@@ -188,7 +188,9 @@ smmc::KernelArgs make_args(const smmc_engine *e, const smmc_sim *s) {
   a.mode = s->mode;
   a.table_a = s->mode == SMMC_MODE_TABLE ? e->d_table : nullptr;
   a.table_len = s->mode == SMMC_MODE_TABLE ? e->table_len : 0u;
-  a.bm_tables = e->d_bm_tables;
+  a.stream = (s->flags & SMMC_FLAG_STREAM_V2) ? 2 : 3;
+  // d_bm_tables holds v2's radius + trig tables, then v3's
+  a.bm_tables = a.stream == 2 ? e->d_bm_tables : e->d_bm_tables + smmc::bm_tables_bytes(2) / sizeof(float);
   a.key0 = static_cast<uint32_t>(s->seed);
   a.key1 = static_cast<uint32_t>(s->seed >> 32);
   a.first_path = s->first_path;
@@ -197,6 +199,7 @@ smmc::KernelArgs make_args(const smmc_engine *e, const smmc_sim *s) {
   a.initial_capital = s->initial_capital;
   a.gauss_mean = s->gauss_mean;
   a.gauss_std = s->gauss_std;
+  a.gauss_shift100 = 100.0f + s->gauss_mean;
   a.n_bins = s->n_bins;
   a.hist_lo = s->hist_lo;
   a.hist_hi = s->hist_hi;
@@ -241,7 +244,7 @@ int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float 
     a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
   }
   if (grid > 0) {
-    const size_t lds = smmc::paths_lds_bytes(a.table_len, d_stats ? s->n_bins : 0u);
+    const size_t lds = smmc::paths_lds_bytes(a.table_len, d_stats ? s->n_bins : 0u, a.stream);
     if (lds + 2048 > e->max_lds)
       return fail(SMMC_ERR_INVALID, "table + histogram need %zu bytes of LDS, device allows %zu", lds, e->max_lds);
     int rc = timing_begin(e);
@@ -346,18 +349,35 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     smmc_engine_destroy(e);
     return fail(SMMC_ERR_HIP, "hipMalloc(partials) failed: %s", hipGetErrorString(err));
   }
-  // Box-Muller tables: radius cubics then (cos, sin) pairs, as the kernels stage them
-  static_assert(sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig) == (1056 * 4 + 256 * 2) * 4, "table layout");
-  if (smmc::bm_tables_bytes() != sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig)) {
+  {
+    // the Gaussian kernels read counter stream v3's tables at absolute LDS addresses from 0
+    size_t static_lds = 0;
+    err = smmc::static_lds_bytes(&static_lds);
+    if (err != hipSuccess || static_lds != 0) {
+      smmc_engine_destroy(e);
+      return fail(SMMC_ERR_INVALID, "a Gaussian kernel has %zu bytes of static LDS (%s); the draw tables must start at LDS address 0",
+                  static_lds, hipGetErrorString(err));
+    }
+  }
+  // Box-Muller tables, as the kernels stage them: radius cubics then (cos, sin) pairs, counter stream
+  // v2's set first, then v3's
+  static_assert(sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig) == (1056 * 4 + 256 * 2) * 4, "v2 table layout");
+  static_assert(sizeof(smmc_bm3_radius) + sizeof(smmc_bm3_trig) == (1024 * 4 + 512 * 2) * 4, "v3 table layout");
+  if (smmc::bm_tables_bytes(2) != sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig) ||
+      smmc::bm_tables_bytes(3) != sizeof(smmc_bm3_radius) + sizeof(smmc_bm3_trig)) {
     smmc_engine_destroy(e);
     return fail(SMMC_ERR_INVALID, "Box-Muller table size mismatch between host and kernels");
   }
-  err = hipMalloc(reinterpret_cast<void **>(&e->d_bm_tables), smmc::bm_tables_bytes());
-  if (err == hipSuccess)
-    err = hipMemcpy(e->d_bm_tables, smmc_bm_radius, sizeof(smmc_bm_radius), hipMemcpyHostToDevice);
-  if (err == hipSuccess)
-    err = hipMemcpy(reinterpret_cast<char *>(e->d_bm_tables) + sizeof(smmc_bm_radius), smmc_bm_trig,
-                    sizeof(smmc_bm_trig), hipMemcpyHostToDevice);
+  err = hipMalloc(reinterpret_cast<void **>(&e->d_bm_tables), smmc::bm_tables_bytes(2) + smmc::bm_tables_bytes(3));
+  {
+    char *dst = reinterpret_cast<char *>(e->d_bm_tables);
+    const void *parts[4] = {smmc_bm_radius, smmc_bm_trig, smmc_bm3_radius, smmc_bm3_trig};
+    const size_t sizes[4] = {sizeof(smmc_bm_radius), sizeof(smmc_bm_trig), sizeof(smmc_bm3_radius), sizeof(smmc_bm3_trig)};
+    for (int i = 0; i < 4 && err == hipSuccess; ++i) {
+      err = hipMemcpy(dst, parts[i], sizes[i], hipMemcpyHostToDevice);
+      dst += sizes[i];
+    }
+  }
   if (err != hipSuccess) {
     smmc_engine_destroy(e);
     return fail(SMMC_ERR_HIP, "uploading the Box-Muller tables failed: %s", hipGetErrorString(err));
@@ -469,8 +489,9 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   if (comb_fits) {
     const size_t lds_cu = 160u * 1024u;
     const uint32_t tl = sim->mode == SMMC_MODE_TABLE ? e->table_len : 0u;
-    const size_t fixed = smmc::keepdata_comb_lds_bytes(tl, 0);
-    const size_t per_wave = smmc::keepdata_comb_lds_bytes(tl, 1) - fixed;
+    const int strm = (sim->flags & SMMC_FLAG_STREAM_V2) ? 2 : 3;
+    const size_t fixed = smmc::keepdata_comb_lds_bytes(tl, 0, strm);
+    const size_t per_wave = smmc::keepdata_comb_lds_bytes(tl, 1, strm) - fixed;
     comb_waves = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 16)) : 0;
     if (sim->mode == SMMC_MODE_TABLE && comb_waves > 12) comb_waves = 12;
     if (const char *env = std::getenv("SMMC_KEEPDATA_COMB_WAVES")) {  // tuning knob
@@ -539,8 +560,8 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
       if (v == 16 || v == 32) tile = static_cast<int>(v);
     }
     const size_t lds_cu = 160u * 1024u;
-    const size_t fixed = smmc::keepdata_lds_bytes(a.table_len, tile, 0);
-    const size_t per_wave = smmc::keepdata_lds_bytes(a.table_len, tile, 1) - fixed;
+    const size_t fixed = smmc::keepdata_lds_bytes(a.table_len, tile, 0, a.stream);
+    const size_t per_wave = smmc::keepdata_lds_bytes(a.table_len, tile, 1, a.stream) - fixed;
     const int fit = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 12)) : 0;
     if (fit < 1) return fail(SMMC_ERR_INVALID, "keepdata: the table leaves no LDS for a tile");
     int waves = sim->mode == SMMC_MODE_TABLE ? std::min(fit, 4) : (fit >= 12 ? 12 : fit >= 8 ? 8 : std::min(fit, 4));
@@ -548,7 +569,7 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
       const long v = std::strtol(env, nullptr, 10);
       if (v >= 1 && v <= fit) waves = static_cast<int>(v);
     }
-    const size_t lds = smmc::keepdata_lds_bytes(a.table_len, tile, waves);
+    const size_t lds = smmc::keepdata_lds_bytes(a.table_len, tile, waves, a.stream);
     const uint64_t n_wave_chunks = (rest.n_paths + 63) / 64;
     const uint32_t resident = static_cast<uint32_t>(std::max<size_t>(lds_cu / lds, 1));
     const uint32_t per_cu = e->keepdata_blocks_per_cu ? e->keepdata_blocks_per_cu : resident;

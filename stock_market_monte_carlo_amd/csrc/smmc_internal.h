@@ -19,7 +19,7 @@ struct BlockPartial {
 struct KernelArgs {
   int32_t mode;           // SMMC_MODE_*
   const float *table_a;  // device, table_len entries, already 100.0f + r  (MODE_TABLE)
-  const float *bm_tables;  // device, Box-Muller radius + trig tables (MODE_GAUSSIAN), 16-byte aligned
+  const float *bm_tables;  // device, Box-Muller radius + trig tables of the launch's stream (MODE_GAUSSIAN), 16-byte aligned
   uint32_t table_len;
   uint32_t key0, key1;   // Philox key = seed lo, hi
   uint64_t first_path;
@@ -27,6 +27,8 @@ struct KernelArgs {
   uint32_t n_periods;
   float initial_capital;
   float gauss_mean, gauss_std;
+  float gauss_shift100;  // 100.0f + gauss_mean: the additive term of counter stream v3's multiplier draw
+  int32_t stream;        // Gaussian draw: 2 = counter stream v2 (SMMC_FLAG_STREAM_V2), else v3
   float *d_final;        // nullable
   float *d_chunk_mean;   // nullable
   float *d_chunk_var;    // nullable
@@ -94,12 +96,13 @@ hipError_t launch_keepdata_comb(const KernelArgs &a, bool exact_div, int blocks_
                                 unsigned long long *next_chunk, hipStream_t stream);
 hipError_t launch_final_column(const float *traj, uint64_t n_rows, uint32_t row_len, float *d_final, uint32_t grid,
                                hipStream_t stream);
-size_t keepdata_comb_lds_bytes(uint32_t table_len, int waves);
+size_t keepdata_comb_lds_bytes(uint32_t table_len, int waves, int stream);
 uint32_t keepdata_draws(uint32_t table_len);
 hipError_t launch_selftest(uint32_t lo, uint32_t hi, unsigned long long *d_count, uint32_t grid,
                            hipStream_t stream);
-size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins);
-size_t keepdata_lds_bytes(uint32_t table_len, int tile, int waves);
-size_t bm_tables_bytes();
+size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins, int stream);
+size_t keepdata_lds_bytes(uint32_t table_len, int tile, int waves, int stream);
+size_t bm_tables_bytes(int stream);  // 2 | 3
+hipError_t static_lds_bytes(size_t *bytes);  // of the kernels that address the v3 tables absolutely: 0
 
 }  // namespace smmc

@@ -161,7 +161,7 @@ class Engine:
     @staticmethod
     def make_sim(n_paths, n_periods, mode, seed, first_path=0, initial_capital=1000.0, gauss_mean=0.5,
                  gauss_std=0.83333, n_bins=0, hist_lo=0.0, hist_hi=1.0, below_threshold=None,
-                 exact_div=False):
+                 exact_div=False, stream=3):
         s = _lib.Sim()
         s.struct_size = C.sizeof(_lib.Sim)
         s.mode = mode
@@ -176,7 +176,9 @@ class Engine:
         s.hist_lo = hist_lo
         s.hist_hi = hist_hi
         s.below_threshold = initial_capital if below_threshold is None else below_threshold
-        s.flags = _lib.FLAG_EXACT_DIV if exact_div else 0
+        if stream not in (2, 3):
+            raise ValueError("stream must be 2 or 3 (the counter stream of the Gaussian draw)")
+        s.flags = (_lib.FLAG_EXACT_DIV if exact_div else 0) | (_lib.FLAG_STREAM_V2 if stream == 2 else 0)
         return s
 
     def simulate(self, sim, want_final=True, want_chunk_stats=False, want_stats=False, out=None):

@@ -15,11 +15,12 @@ hipError_t launch_keepdata(const KernelArgs &, bool, int, int, uint32_t, hipStre
 hipError_t launch_keepdata_comb(const KernelArgs &, bool, int, uint32_t, uint64_t, uint64_t, int, uint32_t, unsigned long long *,
                                 hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_final_column(const float *, uint64_t, uint32_t, float *, uint32_t, hipStream_t) { return hipErrorNoDevice; }
-size_t keepdata_comb_lds_bytes(uint32_t, int) { return 0; }
+size_t keepdata_comb_lds_bytes(uint32_t, int, int) { return 0; }
 uint32_t keepdata_draws(uint32_t table_len) { return (table_len && table_len <= 2048u) ? 8u : 4u; }
 hipError_t launch_selftest(uint32_t, uint32_t, unsigned long long *, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 uint32_t values_hist_copies(uint32_t) { return 1; }
-size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins) { return (static_cast<size_t>(table_len) + n_bins) * 4u; }
-size_t keepdata_lds_bytes(uint32_t, int, int) { return 0; }
-size_t bm_tables_bytes() { return (1056 * 4 + 256 * 2) * 4; }
+size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins, int) { return (static_cast<size_t>(table_len) + n_bins) * 4u; }
+size_t keepdata_lds_bytes(uint32_t, int, int, int) { return 0; }
+hipError_t static_lds_bytes(size_t *bytes) { *bytes = 0; return hipSuccess; }
+size_t bm_tables_bytes(int stream) { return stream == 2 ? (1056 * 4 + 256 * 2) * 4 : (1024 * 4 + 512 * 2) * 4; }
 }  // namespace smmc
