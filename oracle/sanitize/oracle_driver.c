@@ -48,7 +48,13 @@ int main(void) {
       orc_box_muller_scaled(corners[a], corners[b], 0.83333f, 0.5f, &zc, &zs);
       EXPECT(isfinite(zc) && isfinite(zs));
       EXPECT(orc_bm_radius(corners[a]) >= 0.0f);
+      orc_box_muller3(corners[a], corners[b], &zc, &zs);
+      EXPECT(isfinite(zc) && isfinite(zs) && fabsf(zc) < 7.0f && fabsf(zs) < 7.0f);
+      orc_box_muller3_scaled(corners[a], corners[b] ^ 0x00400000u, 0.83333f, 100.5f, &zc, &zs);
+      EXPECT(isfinite(zc) && isfinite(zs));
+      EXPECT(orc_bm3_radius(corners[a]) >= 0.0f);
     }
+  EXPECT(orc_bm3_radius_scan(0, 1ull << 32, 1000003) < 1e-6);
   EXPECT(orc_bm_radius_scan(0, 1ull << 32, 1000003) < 1e-6);
 
   /* engine (R) */
@@ -80,6 +86,7 @@ int main(void) {
         p.hist_lo = 0.0f;
         p.hist_hi = 20000.0f;
         p.below_threshold = 1000.0f;
+        p.stream = (pi & 1) ? 2u : 3u;  /* both Gaussian draws (table mode ignores it) */
         orc_stats st;
         EXPECT(orc_counter_mc(&p, fin, hist, &st, traj, 2) == 0);
         EXPECT(st.count == 300);

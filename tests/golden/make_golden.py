@@ -5,8 +5,9 @@
                           library the reference calls at src/simulations.cpp:245-250).
                           This pins the oracle's hand-written mt19937 / Lemire map.
   counter_stream_v2.json  frozen outputs of the oracle's counter-stream engine (C):
-                          regression vectors for the HIP kernels that also travel to
-                          the GPU box.  These are pinned to the oracle itself only.
+  counter_stream_v3.json  regression vectors for the HIP kernels that also travel to
+                          the GPU box (v2: round 1's Gaussian draw, selected with
+                          SMMC_FLAG_STREAM_V2; v3: the default).  Pinned to the oracle itself only.
 
 The reference implementation could not be built here (see oracle/Makefile), so no
 fixture in this directory comes from an executed reference.
@@ -52,27 +53,28 @@ def main():
     pin["table_bits_fnv1a"] = int(fnv1a(table.view(np.uint32)))
     with open(os.path.join(HERE, "libstdcxx_random.json"), "w") as f:
         json.dump(pin, f, indent=1)
-    # --- counter stream v1 regression vectors -----------------------------
-    cases = []
-    for mode, name in ((O.MODE_TABLE, "table"), (O.MODE_GAUSSIAN, "gaussian")):
-        for P in (1, 3, 4, 5, 360, 1000):
-            for first in (0, (1 << 32) - 100):
-                p = O.make_params(mode, P, 300, seed=0x5EED0123456789AB, first_path=first, table=table,
-                                  n_bins=100, hist_lo=0.0, hist_hi=20000.0)
-                r = O.counter_mc(p)
-                st = r["stats"]
-                cases.append({
-                    "mode": name, "n_periods": P, "first_path": first, "n_paths": 300,
-                    "seed": 0x5EED0123456789AB, "initial_capital": 1000.0,
-                    "gauss_mean": 0.5, "gauss_std": float(np.float32(0.83333)),
-                    "n_bins": 100, "hist_lo": 0.0, "hist_hi": 20000.0, "below_threshold": 1000.0,
-                    "final_bits": [int(x) for x in r["final"].view(np.uint32)],
-                    "hist": [int(x) for x in r["hist"]],
-                    "below": int(st.below), "underflow": int(st.underflow), "overflow": int(st.overflow),
-                    "sum": st.sum, "sumsq": st.sumsq, "min": float(st.min), "max": float(st.max),
-                })
-    with open(os.path.join(HERE, "counter_stream_v2.json"), "w") as f:
-        json.dump({"table_bits_fnv1a": int(fnv1a(table.view(np.uint32))), "cases": cases}, f)
+    # --- counter stream regression vectors (v2 = round 1's Gaussian draw, v3 = the default) -------
+    for stream in (2, 3):
+        cases = []
+        for mode, name in ((O.MODE_TABLE, "table"), (O.MODE_GAUSSIAN, "gaussian")):
+            for P in (1, 3, 4, 5, 360, 1000):
+                for first in (0, (1 << 32) - 100):
+                    p = O.make_params(mode, P, 300, seed=0x5EED0123456789AB, first_path=first, table=table,
+                                      n_bins=100, hist_lo=0.0, hist_hi=20000.0, stream=stream)
+                    r = O.counter_mc(p)
+                    st = r["stats"]
+                    cases.append({
+                        "mode": name, "n_periods": P, "first_path": first, "n_paths": 300,
+                        "seed": 0x5EED0123456789AB, "initial_capital": 1000.0,
+                        "gauss_mean": 0.5, "gauss_std": float(np.float32(0.83333)),
+                        "n_bins": 100, "hist_lo": 0.0, "hist_hi": 20000.0, "below_threshold": 1000.0,
+                        "final_bits": [int(x) for x in r["final"].view(np.uint32)],
+                        "hist": [int(x) for x in r["hist"]],
+                        "below": int(st.below), "underflow": int(st.underflow), "overflow": int(st.overflow),
+                        "sum": st.sum, "sumsq": st.sumsq, "min": float(st.min), "max": float(st.max),
+                    })
+        with open(os.path.join(HERE, f"counter_stream_v{stream}.json"), "w") as f:
+            json.dump({"table_bits_fnv1a": int(fnv1a(table.view(np.uint32))), "stream": stream, "cases": cases}, f)
     print("wrote fixtures")
 
 

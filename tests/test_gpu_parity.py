@@ -73,21 +73,54 @@ def test_path_ids_beyond_32_bits_and_seed_halves(eng, oracle, table, mode_name):
         assert np.array_equal(r.final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32)), (first, seed)
 
 
-def test_golden_counter_stream(eng, table):
-    """Frozen oracle outputs (tests/golden/counter_stream_v2.json, made by make_golden.py)."""
+@pytest.mark.parametrize("stream", [2, 3])
+def test_golden_counter_stream(eng, table, stream):
+    """Frozen oracle outputs (tests/golden/counter_stream_v{2,3}.json, made by make_golden.py): v3 is
+    the default Gaussian draw, v2 (round 1's) is selected with SMMC_FLAG_STREAM_V2."""
     from stock_market_monte_carlo_amd import Engine
-    with open(os.path.join(HERE, "golden", "counter_stream_v2.json")) as f:
+    with open(os.path.join(HERE, "golden", f"counter_stream_v{stream}.json")) as f:
         gold = json.load(f)
     for c in gold["cases"]:
         sim = Engine.make_sim(c["n_paths"], c["n_periods"], _modes()[c["mode"]], c["seed"], first_path=c["first_path"],
                               initial_capital=c["initial_capital"], gauss_mean=c["gauss_mean"], gauss_std=c["gauss_std"],
                               n_bins=c["n_bins"], hist_lo=c["hist_lo"], hist_hi=c["hist_hi"],
-                              below_threshold=c["below_threshold"])
+                              below_threshold=c["below_threshold"], stream=stream)
         r = eng.simulate(sim, want_stats=True)
         st = eng.read_stats(r.stats_raw)
         assert [int(x) for x in r.final.cpu().numpy().view(np.uint32)] == c["final_bits"], (c["mode"], c["n_periods"])
         assert [int(x) for x in st.hist] == c["hist"]
         assert (st.below, st.underflow, st.overflow) == (c["below"], c["underflow"], c["overflow"])
+
+
+def test_stream_v2_stays_selectable_in_every_kernel(eng, oracle, table, monkeypatch):
+    """SMMC_FLAG_STREAM_V2: round 1's Gaussian draw through the paths kernel (fast, checked and IEEE
+    divide), both keepdata kernels and the host pipeline, bit-exact against the oracle's v2 engine."""
+    from stock_market_monte_carlo_amd import Engine, MODE_GAUSSIAN
+    for n, p, kw in ((3000, 360, {}), (1000, 1000, {}), (777, 37, {"exact_div": True}),
+                     (2000, 360, {"gauss_mean": 2.0, "gauss_std": 9.0})):  # the last one: range-checked divide
+        sim = Engine.make_sim(n, p, MODE_GAUSSIAN, SEED, first_path=5, n_bins=64, hist_lo=0.0, hist_hi=30000.0, stream=2, **kw)
+        r = eng.simulate(sim, want_stats=True)
+        st = eng.read_stats(r.stats_raw)
+        op = oracle.make_params(oracle.MODE_GAUSSIAN, p, n, SEED, first_path=5, n_bins=64, hist_lo=0.0, hist_hi=30000.0,
+                                stream=2, gauss_mean=kw.get("gauss_mean", 0.5), gauss_std=kw.get("gauss_std", 0.83333))
+        o = oracle.counter_mc(op)
+        assert np.array_equal(r.final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32)), (n, p, kw)
+        assert np.array_equal(st.hist, o["hist"]) and st.below == o["stats"].below
+        # and v3 on the same request really is another stream
+        sim3 = Engine.make_sim(n, p, MODE_GAUSSIAN, SEED, first_path=5, **kw)
+        assert not np.array_equal(eng.simulate(sim3).final.cpu().numpy(), o["final"])
+    for kernel, n, p in (("tile", 700, 360), ("comb", 2048 + 300, 64)):
+        monkeypatch.setenv("SMMC_KEEPDATA_KERNEL", kernel)
+        sim = Engine.make_sim(n, p, MODE_GAUSSIAN, SEED, first_path=11, stream=2)
+        traj, final = eng.simulate_keepdata(sim)
+        o = oracle.counter_mc(oracle.make_params(oracle.MODE_GAUSSIAN, p, n, SEED, first_path=11, stream=2), want_traj=True)
+        assert np.array_equal(traj.cpu().numpy().view(np.uint32), o["traj"].view(np.uint32)), kernel
+        assert np.array_equal(final.cpu().numpy().view(np.uint32), o["final"].view(np.uint32))
+    monkeypatch.delenv("SMMC_KEEPDATA_KERNEL")
+    sim = Engine.make_sim(5000, 24, MODE_GAUSSIAN, SEED, stream=2)
+    host, _, _ = eng.simulate_to_host(sim)
+    o = oracle.counter_mc(oracle.make_params(oracle.MODE_GAUSSIAN, 24, 5000, SEED, stream=2))
+    assert np.array_equal(host.view(np.uint32), o["final"].view(np.uint32))
 
 
 @pytest.mark.parametrize("mode_name", ["table", "gaussian"])

@@ -38,7 +38,7 @@ def test_box_muller_tables_identical_in_oracle_and_product():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     a = open(os.path.join(root, "oracle", "smmc_bm_tables.inc")).read()
     b = open(os.path.join(root, "stock_market_monte_carlo_amd", "csrc", "smmc_bm_tables.inc")).read()
-    assert a == b and "SMMC_BM_RADIUS_ENTRIES 1056" in a
+    assert a == b and "SMMC_BM_RADIUS_ENTRIES 1056" in a and "SMMC_BM3_RADIUS_ENTRIES 1024" in a
 
 
 def test_box_muller_moments_and_accuracy(oracle):
@@ -65,6 +65,76 @@ def test_box_muller_moments_and_accuracy(oracle):
     assert oracle.box_muller(0, 0) == (oracle.bm_radius(0), 0.0)
     zc, zs = oracle.box_muller(0, 0x40000000)
     assert zc == 0.0 and zs == oracle.bm_radius(0)
+
+
+def test_stream_v3_radius_table_accuracy(oracle):
+    """Counter stream v3's radius: f = fl(w | 1), u = f / 2^32 in (0, 1/2], 32 octaves stored rotated so
+    that the bin is one bit-field of f, cubic in x' in [-1/32, 1/32).  Same bound as v2's table."""
+    assert oracle.bm3_radius_scan(0, 2 ** 32, 499) < 6e-7
+    assert oracle.bm3_radius_scan(0, 1 << 20, 1) < 6e-7                       # deepest tail, every value
+    assert oracle.bm3_radius_scan((1 << 32) - (1 << 20), 1 << 32, 1) < 6e-7  # U -> 1 end (sqrt singularity)
+    assert oracle.bm3_radius_scan((1 << 31) - (1 << 18), (1 << 31) + (1 << 18), 1) < 6e-7  # where the sides meet
+    # octave boundaries: every power of two of the distance, both neighbours, both sides
+    edges = [v for e in range(1, 31) for v in ((1 << e) - 1, 1 << e, (1 << e) + 1)]
+    for side in (0, 0xFFFFFFFF):
+        got = np.array([oracle.bm3_radius((w ^ side) & 0xFFFFFFFF) for w in edges])
+        u = np.array([float(np.float32(w | 1)) for w in edges]) / 2.0 ** 32
+        want = np.sqrt(-2 * np.log1p(-u)) if side else np.sqrt(-2 * np.log(u))
+        assert np.abs(got - want).max() < 6e-7
+    assert oracle.bm3_radius(0) == max(oracle.bm3_radius(a) for a in (0, 1, 2, 1000, 2 ** 31))
+    assert abs(oracle.bm3_radius(0) - np.sqrt(-2 * np.log(2.0 ** -32))) < 1e-6  # 6.66 sigma
+    assert 0 < oracle.bm3_radius(0xFFFFFFFF) < 3e-5
+    assert oracle.bm3_radius(0x7FFFFFFF) == oracle.bm3_radius(0x80000000)   # u = 1/2 from either side
+
+
+def test_stream_v3_box_muller_moments_and_accuracy(oracle):
+    rng = np.random.default_rng(5)
+    ua = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64)
+    ub = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64)
+    z = np.array([oracle.box_muller3(int(a), int(b)) for a, b in zip(ua, ub)])
+    mask = np.where(ua >> 31, np.uint64(0xFFFFFFFF), np.uint64(0))
+    u = ((ua ^ mask) | np.uint64(1)).astype(np.float32).astype(np.float64) / 2.0 ** 32
+    r = np.where(ua >> 31, np.sqrt(-2 * np.log1p(-u)), np.sqrt(-2 * np.log(u)))
+    th = 2 * np.pi * ub.astype(np.float64) / 2.0 ** 32
+    # |dz|: radius table 4.1e-7 + sin(delta) = delta (3.9e-8 x r) + binary32 roundings
+    assert np.abs(z[:, 0] - r * np.cos(th)).max() < 1.2e-6
+    assert np.abs(z[:, 1] - r * np.sin(th)).max() < 1.2e-6
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    # the scaled form: the kernels draw the MULTIPLIER fma(r std, cos, 100 + mean)
+    zc, zs = oracle.box_muller3(123456789, 987654321)
+    dc, ds = oracle.box_muller3_scaled(123456789, 987654321, 0.83333, 100.5)
+    assert dc == pytest.approx(100.5 + 0.83333 * zc, abs=1e-5) and ds == pytest.approx(100.5 + 0.83333 * zs, abs=1e-5)
+    for a, b in [(0, 0), (0xFFFFFFFF, 0xFFFFFFFF), (0, 0x80000000), (0xFFFFFFFF, 0x40000000), (1, 0x3FFFFFFF),
+                 (0x7FFFFFFF, 0x003FFFFF), (0x80000000, 0x00400000), (0x12345678, 0xFFC00000), (5, 0xFFFFFFFF)]:
+        zc, zs = oracle.box_muller3(a, b)
+        assert np.isfinite(zc) and np.isfinite(zs) and abs(zc) < 7 and abs(zs) < 7
+        assert abs(np.hypot(zc, zs) - oracle.bm3_radius(a)) < 1e-5 * (1 + oracle.bm3_radius(a))
+    # angle 0 and the quarter turns come out exact; the index wraps at a full turn
+    assert oracle.box_muller3(0, 0) == (oracle.bm3_radius(0), 0.0)
+    zc, zs = oracle.box_muller3(0, 0x40000000)
+    assert zc == 0.0 and zs == oracle.bm3_radius(0)
+    zc, zs = oracle.box_muller3(0, 0xFFFFFFFF)  # 2 pi - epsilon: table entry 0 again, delta = -2 pi / 2^32
+    assert zc == oracle.bm3_radius(0) and abs(zs) < 1e-8
+
+
+def test_stream_v3_return_is_the_multiplier_minus_100(oracle, table):
+    """v3 draws the multiplier a; the period return it reports is a - 100, exact by Sterbenz for
+    a in [50, 200], so update_fund(total, return) reproduces the engine's step bit for bit: the
+    trajectory IS many_updates of the reported returns (src/simulations.cpp:18-22)."""
+    p = oracle.make_params(oracle.MODE_GAUSSIAN, 360, 4, 99, first_path=12345)
+    r = oracle.counter_mc(p, want_traj=True)
+    for i in range(4):
+        rets = oracle.counter_path_returns(p, 12345 + i)
+        assert np.array_equal(oracle.many_updates(1000.0, rets, 360).view(np.uint32), r["traj"][i].view(np.uint32))
+    # and the two streams are different transforms of the same uniforms: close, not equal
+    p2 = oracle.make_params(oracle.MODE_GAUSSIAN, 360, 4, 99, first_path=12345, stream=2)
+    r2 = oracle.counter_path_returns(p2, 12345)
+    r3 = oracle.counter_path_returns(p, 12345)
+    assert not np.array_equal(r2, r3) and np.abs(r2 - r3).max() < 2e-5
+    # table mode does not depend on the stream version
+    t3 = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 72, 50, 7, table=table))["final"]
+    t2 = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 72, 50, 7, table=table, stream=2))["final"]
+    assert np.array_equal(t2.view(np.uint32), t3.view(np.uint32))
 
 
 def test_histogram_bucket_contract(oracle):
