@@ -270,15 +270,16 @@ ORC_API float orc_bm3_radius(uint32_t ua) {
   return fmaf(fmaf(fmaf(k[3], x, k[2]), x, k[1]), x, k[0]);
 }
 
-/* Angle: 512-entry table, theta = 2 pi i / 512 + delta, i = (ub + 2^22) >> 23 (mod 512),
- * delta = sext23(ub) * 2 pi / 2^32, |delta| <= pi/512 = 6.1e-3: sin(delta) = delta (error
- * delta^3/6 <= 3.9e-8), cos(delta) = 1 - delta^2/2 (error 6e-11).  |dz| < 1.1e-6 vs double for
+/* Angle: theta = 2 pi ub / 2^32 = 2 pi (i + 1/2) / 512 + delta with i = ub >> 23 (no rounding add:
+ * the 512 table angles sit at the middle of their sectors) and delta = (low 23 bits - 2^22) 2 pi / 2^32
+ * in [-pi/512, pi/512), formed by one fma from the converted low bits (exactly 0 at the sector's
+ * middle: 2^22 C and pi/512 have the same binary32 mantissa).  |delta| <= 6.1e-3: sin(delta) = delta
+ * (error delta^3/6 <= 3.9e-8), cos(delta) = 1 - delta^2/2 (error 6e-11).  |dz| < 1.2e-6 vs double for
  * scale = 1 (tests/test_numerics_cpu.py). */
 ORC_API void orc_box_muller3_scaled(uint32_t ua, uint32_t ub, float scale, float shift, float *d_cos, float *d_sin) {
   float rs = orc_bm3_radius(ua) * scale;
-  uint32_t i = (ub + 0x00400000u) >> 23;
-  int32_t d = (int32_t)(ub << 9) >> 9; /* low 23 bits, sign-extended */
-  float delta = (float)d * 0x1.921fb6p-30f;
+  uint32_t i = ub >> 23;
+  float delta = fmaf((float)(ub & 0x007fffffu), 0x1.921fb6p-30f, -0x1.921fb6p-8f);
   float cd = fmaf(delta * delta, -0.5f, 1.0f);
   float ci = smmc_bm3_trig[i][0], si = smmc_bm3_trig[i][1];
   float ct = fmaf(-si, delta, ci * cd);

@@ -78,7 +78,9 @@ def v3_tables():
             p, err = fit_bin3(side, c, 0 if c == OCT3 - 1 else j)
             worst = max(worst, err)
             rows.append(p)
-    trig = [(np.cos(2 * np.pi * i / 512), np.sin(2 * np.pi * i / 512)) for i in range(512)]
+    # angles at the MIDDLE of each of the 512 sectors: the index is then ub >> 23 with no rounding add,
+    # and the residual angle (low 23 bits - 2^22) 2 pi / 2^32 lies in [-pi/512, pi/512)
+    trig = [(np.cos(2 * np.pi * (i + 0.5) / 512), np.sin(2 * np.pi * (i + 0.5) / 512)) for i in range(512)]
     return rows, trig, worst
 
 
