@@ -517,11 +517,12 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     a.d_final = nullptr;
     a.n_paths = n_comb;
     const int waves = comb_waves;
-    // rows per stream.  More rows cost fewer extra columns (4.3 % at K = 1, 2.1 % at K = 2, 1.1 % at
-    // K = 4 for P = 360) but make the chunks a wave takes coarser.  Measured (tools/kd_ab.py, 4e6 x 361):
-    // Gaussian, where the columns cost arithmetic, K = 2 (1.300 ms; K = 1 1.318, K = 4 1.45);
-    // table mode, bound by the stores, K = 1 (1.106 ms; K = 2 1.124).
-    uint32_t k_rows = sim->mode == SMMC_MODE_GAUSSIAN ? 2 : 1;
+    // rows per stream.  More rows cost fewer extra columns (4.3 % at K = 1, 2.1 % at K = 2 for P = 360)
+    // but make the chunks a wave takes coarser.  Measured (tools/kd_ab.py, stream v3): Gaussian, where
+    // the columns cost arithmetic, 4e6 x 361: K = 2 1.198 ms, K = 1 1.214; 1.5e6 x 1001 (3 chunks per
+    // wave at K = 2): K = 1 1.339 ms, K = 2 1.412.  Table mode, bound by the stores: K = 1.
+    uint32_t k_rows = 1;
+    if (sim->mode == SMMC_MODE_GAUSSIAN && n_super * 16u >= 8ull * e->compute_units * static_cast<uint64_t>(waves)) k_rows = 2;
     if (const char *env = std::getenv("SMMC_KEEPDATA_K")) {  // tuning knob: 1, 2, 4, 8, 16 or 32
       const long v = std::strtol(env, nullptr, 10);
       if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k_rows = static_cast<uint32_t>(v);
