@@ -29,7 +29,8 @@
  *       follows src/simulations.cpp:204-266 with deterministic per-path seeds
  *       (the reference seeds from std::random_device and has no seed argument).
  *       This is what bench.py times as the CPU baseline ("port").
- *   (C) "counter stream v2": Philox4x32-10 keyed by the 64-bit seed, counter =
+ *   (C) "counter stream v3" (default; v2's Gaussian draw with orc_params.stream = 2):
+ *       Philox4x32-10 keyed by the 64-bit seed, counter =
  *       (global path id, step block, stream tag); table-indexed (eight draws per
  *       block for tables <= 2048 entries) or Box-Muller Gaussian draws; the same
  *       three-rounding compounding step.  The HIP

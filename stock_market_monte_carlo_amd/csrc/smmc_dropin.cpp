@@ -87,6 +87,9 @@ smmc_sim make_sim(int mode, std::uint64_t seed, std::uint64_t first, std::uint64
   s.gauss_mean = 0.5f;
   s.gauss_std = 0.83333f;
   s.below_threshold = capital;
+  // SMMC_STREAM=2: the Gaussian draw of counter stream v2 (round 1) for callers that hold v2 results
+  if (const char *env = std::getenv("SMMC_STREAM"))
+    if (env[0] == '2' && env[1] == '\0') s.flags |= SMMC_FLAG_STREAM_V2;
   return s;
 }
 
