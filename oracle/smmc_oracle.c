@@ -253,38 +253,50 @@ ORC_API void orc_box_muller(uint32_t ua, uint32_t ub, float *z_cos, float *z_sin
   orc_box_muller_scaled(ua, ub, 1.0f, 0.0f, z_cos, z_sin);
 }
 
-/* ---- counter stream v3: the same construction with cheaper index arithmetic -------------------
- * (round 2: the Gaussian path step is bound by VALU instruction count; v3 needs 26 instead of 30.5
- * per period on the device.  Table mode is the same in v2 and v3.)
+/* ---- counter stream v3: the same construction with cheaper arithmetic ---------------------------
+ * (round 2: the Gaussian path step is bound by VALU instruction count; v2 needs 30.5 per period on
+ * the device, v3 23.  Table mode is the same in v2 and v3.)
  * Radius: w = ua ^ (ua >>a 31) as before, f = (float)(w | 1) (one three-input bit operation on the
- * device), u = f / 2^32 in (0, 1/2]: exponent 127 .. 158, 32 octaves x 16 sub-intervals per side,
- * stored rotated so that the table index is ONE bit-field: (bits >> 19) & 511, side at +512.  The
- * cubic's argument is x' = as_float(0x3f800000 | low 19 mantissa bits) - (1 + 1/32), in
- * [-1/32, 1/32): no shift (the coefficients carry the factor 16^k).  Tail: u >= 2^-32, 6.66 sigma. */
-ORC_API float orc_bm3_radius(uint32_t ua) {
+ * device), u = f / 2^32 in (0, 1/2]: exponent 127 .. 158, 32 octaves x 2^SUB_BITS sub-intervals per
+ * side, stored rotated so that the table index is ONE bit-field of f, side OR-ed in above it.  The
+ * cubic is in y = as_float(0x3f800000 | low mantissa bits), in [1, 1 + 2^-SUB_BITS), as the OR leaves
+ * it: the coefficients carry the shift to the bin's middle.  Tail: u >= 2^-32, 6.66 sigma. */
+#define BM3_LOW_BITS (23 - SMMC_BM3_SUB_BITS)
+#define BM3_SIDE_ENTRIES (32u << SMMC_BM3_SUB_BITS)
+/* r * scale as the kernels form it: every coefficient times scale, rounded once (the device does that
+ * while it stages the table in LDS), then the cubic -- the draw needs no multiply of its own.
+ * scale = 1 is the radius itself. */
+ORC_API float orc_bm3_radius_scaled(uint32_t ua, float scale) {
   uint32_t mask = (uint32_t)((int32_t)ua >> 31);
   uint32_t w1 = (ua ^ mask) | 1u;               /* odd, in [1, 2^31) */
   uint32_t bits = f2u((float)w1);               /* round to nearest even, exponent 127 .. 158 */
-  uint32_t entry = ((bits >> 19) & 511u) | (mask & 512u);
-  float x = u2f(0x3f800000u | (bits & 0x0007ffffu)) - 1.03125f; /* exact */
+  uint32_t entry = ((bits >> BM3_LOW_BITS) & (BM3_SIDE_ENTRIES - 1u)) | (mask & BM3_SIDE_ENTRIES);
+  float y = u2f(0x3f800000u | (bits & ((1u << BM3_LOW_BITS) - 1u)));
   const float *k = smmc_bm3_radius[entry];
-  return fmaf(fmaf(fmaf(k[3], x, k[2]), x, k[1]), x, k[0]);
+  float k0 = k[0] * scale, k1 = k[1] * scale, k2 = k[2] * scale, k3 = k[3] * scale;
+  return fmaf(fmaf(fmaf(k3, y, k2), y, k1), y, k0);
 }
 
-/* Angle: theta = 2 pi ub / 2^32 = 2 pi (i + 1/2) / 512 + delta with i = ub >> 23 (no rounding add:
- * the 512 table angles sit at the middle of their sectors) and delta = (low 23 bits - 2^22) 2 pi / 2^32
- * in [-pi/512, pi/512), formed by one fma from the converted low bits (exactly 0 at the sector's
- * middle: 2^22 C and pi/512 have the same binary32 mantissa).  |delta| <= 6.1e-3: sin(delta) = delta
- * (error delta^3/6 <= 3.9e-8), cos(delta) = 1 - delta^2/2 (error 6e-11).  |dz| < 1.2e-6 vs double for
- * scale = 1 (tests/test_numerics_cpu.py). */
+ORC_API float orc_bm3_radius(uint32_t ua) { return orc_bm3_radius_scaled(ua, 1.0f); }
+
+/* Angle: theta = 2 pi ub / 2^32 = theta_i + delta, theta_i the MIDDLE of sector i = ub >> (32 -
+ * TRIG_BITS) (no rounding add) and delta = (low bits - half a sector) 2 pi / 2^32, |delta| <= dmax =
+ * pi / 2^TRIG_BITS, formed WITHOUT an integer-to-float conversion: the low bits are OR-ed into the
+ * mantissa of 1.0f and one fma scales and centres them.  The table's (cos, sin) are rotated by delta to
+ * FIRST order, (c - s delta, s + c delta): a vector at angle theta_i + atan(delta) (off by delta^3/3
+ * <= 1.2e-9) of length sqrt(1 + delta^2); the table carries kappa = 1/sqrt(1 + dmax^2/3), which makes
+ * the mean square length 1, so a draw is r cos(theta) times a factor within -3.9e-7 .. +7.8e-7 of 1
+ * that depends on where in its sector the angle falls (2048 sectors).  Against a second-order rotation
+ * this saves 4 of 25 instructions per pair; the factor is below the binary32 rounding of the draw
+ * itself (tests/test_numerics_cpu.py states the bounds). */
 ORC_API void orc_box_muller3_scaled(uint32_t ua, uint32_t ub, float scale, float shift, float *d_cos, float *d_sin) {
-  float rs = orc_bm3_radius(ua) * scale;
-  uint32_t i = ub >> 23;
-  float delta = fmaf((float)(ub & 0x007fffffu), 0x1.921fb6p-30f, -0x1.921fb6p-8f);
-  float cd = fmaf(delta * delta, -0.5f, 1.0f);
+  float rs = orc_bm3_radius_scaled(ua, scale);
+  uint32_t i = ub >> (32 - SMMC_BM3_TRIG_BITS);
+  float y = u2f(0x3f800000u | (ub & ((1u << (32 - SMMC_BM3_TRIG_BITS)) - 1u)));
+  float delta = fmaf(y, SMMC_BM3_ANGLE_K, -SMMC_BM3_ANGLE_C);
   float ci = smmc_bm3_trig[i][0], si = smmc_bm3_trig[i][1];
-  float ct = fmaf(-si, delta, ci * cd);
-  float st = fmaf(ci, delta, si * cd);
+  float ct = fmaf(-si, delta, ci);
+  float st = fmaf(ci, delta, si);
   *d_cos = fmaf(rs, ct, shift);
   *d_sin = fmaf(rs, st, shift);
 }

@@ -362,7 +362,7 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
   // Box-Muller tables, as the kernels stage them: radius cubics then (cos, sin) pairs, counter stream
   // v2's set first, then v3's
   static_assert(sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig) == (1056 * 4 + 256 * 2) * 4, "v2 table layout");
-  static_assert(sizeof(smmc_bm3_radius) + sizeof(smmc_bm3_trig) == (1024 * 4 + 512 * 2) * 4, "v3 table layout");
+  static_assert(sizeof(smmc_bm3_radius) + sizeof(smmc_bm3_trig) == (512 * 4 + 2048 * 2) * 4, "v3 table layout");
   if (smmc::bm_tables_bytes(2) != sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig) ||
       smmc::bm_tables_bytes(3) != sizeof(smmc_bm3_radius) + sizeof(smmc_bm3_trig)) {
     smmc_engine_destroy(e);

@@ -34,13 +34,28 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 // Philox4x32-10 (Salmon et al., SC'11).  The key schedule is wave-uniform and
 // lives in SGPRs; per round the lanes pay two 32x32->64 multiplies
 // (v_mad_u64_u32) and two three-input XORs (v_bitop3_b32).
+// kUniformBlock: the caller's c2 (the block index) is wave-uniform.
+template <bool kUniformBlock = false>
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = static_cast<uint64_t>(kPhiloxM0) * c0;
     const uint64_t p1 = static_cast<uint64_t>(kPhiloxM1) * c2;
-    const uint32_t n0 = xor3(static_cast<uint32_t>(p1 >> 32), c1, k0);
+    // Rounds 0 and 1 as two plain XORs: with the counter (path, block, mode) and a wave-uniform
+    // block index two of the three terms of their first XOR are wave-uniform (round 0: hi(M1 block)
+    // and k0; round 1: lo(M1 block) and k0'); paired in one SALU XOR they leave one two-input VALU XOR
+    // (a v_bitop3 would need a v_mov in front of it: an instruction reads at most one SGPR).  Round
+    // 1's pair the compiler finds; round 0's it re-associates away unless the pair is opaque to it.
+    const uint32_t h1 = static_cast<uint32_t>(p1 >> 32);
+    uint32_t n0;
+    if (r == 0 && kUniformBlock) {
+      uint32_t uniform_pair = h1 ^ k0;
+      asm("" : "+s"(uniform_pair));
+      n0 = uniform_pair ^ c1;
+    } else {
+      n0 = r < 2 ? ((h1 ^ k0) ^ c1) : xor3(h1, c1, k0);
+    }
     const uint32_t n2 = xor3(static_cast<uint32_t>(p0 >> 32), c3, k1);
     c1 = static_cast<uint32_t>(p1);
     c3 = static_cast<uint32_t>(p0);
@@ -60,7 +75,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // other), so that one wave has 2 N multiplies and 2 N XORs in flight per round instead of 2 + 2.
 // A wave alone can issue a dependent VALU instruction only every 4-8 cycles; below ~6 waves per SIMD
 // this instruction-level parallelism is what fills the issue slots.
-template <int N>
+template <int N, bool kUniformBlock = false>
 __device__ __forceinline__ void philox4x32_10_multi(uint32_t (&c)[N][4], uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
@@ -72,7 +87,15 @@ __device__ __forceinline__ void philox4x32_10_multi(uint32_t (&c)[N][4], uint32_
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const uint32_t n0 = xor3(static_cast<uint32_t>(p1[i] >> 32), c[i][1], k0);
+      const uint32_t h1 = static_cast<uint32_t>(p1[i] >> 32);
+      uint32_t n0;  // rounds 0 and 1: see philox4x32_10
+      if (r == 0 && kUniformBlock) {
+        uint32_t uniform_pair = h1 ^ k0;
+        asm("" : "+s"(uniform_pair));
+        n0 = uniform_pair ^ c[i][1];
+      } else {
+        n0 = r < 2 ? ((h1 ^ k0) ^ c[i][1]) : xor3(h1, c[i][1], k0);
+      }
       const uint32_t n2 = xor3(static_cast<uint32_t>(p0[i] >> 32), c[i][3], k1);
       c[i][1] = static_cast<uint32_t>(p1[i]);
       c[i][3] = static_cast<uint32_t>(p0[i]);
@@ -120,8 +143,9 @@ __device__ __forceinline__ float compound(float total, float a) {
 // and single IEEE operations only: bit-identical to the oracle's C version.
 constexpr uint32_t kBmRadiusEntries = 1056, kBmTrigEntries = 256;
 constexpr uint32_t kBmFloats = kBmRadiusEntries * 4 + kBmTrigEntries * 2;
-// counter stream v3 (the default Gaussian draw): 2 x 512 radius bins, 512 angles
-constexpr uint32_t kBm3RadiusEntries = 1024, kBm3TrigEntries = 512;
+// counter stream v3 (the default Gaussian draw): 2 x 256 radius bins (8 KiB), 2048 sectors (16 KiB)
+// (kBm3SubBits, kBm3TrigBits, kBm3AngleK, kBm3AngleC: smmc_internal.h, checked against the generated tables)
+constexpr uint32_t kBm3RadiusEntries = 64u << kBm3SubBits, kBm3TrigEntries = 1u << kBm3TrigBits;
 constexpr uint32_t kBm3Floats = kBm3RadiusEntries * 4 + kBm3TrigEntries * 2;
 // The kernels' kMode template argument: SMMC_MODE_TABLE (0), SMMC_MODE_GAUSSIAN (1: counter stream
 // v3) or kModeGaussianV2 (the v2 draw, SMMC_FLAG_STREAM_V2).  The Philox counter's mode word is 1
@@ -173,18 +197,20 @@ __device__ __forceinline__ void box_muller_scaled(const float *lds_bm, uint32_t 
   bm_finish(bm_issue(lds_bm, ua, ub), scale, shift, d_cos, d_sin);
 }
 
-// Counter stream v3: the same construction with cheaper index arithmetic (13
-// instead of 16.5 VALU per draw).  The distance w of the
-// uniform from the nearer end goes to binary32 as w | 1 (one v_bitop3 with the XOR that forms w); the
-// radius bin is ONE bit-field of the float -- (bits >> 19) & 511, the octaves are stored rotated --
-// with the side OR-ed in at 512; the cubic's argument needs no shift (its coefficients carry the
-// factor 16^k); the angle table has 512 entries at the MIDDLE of their sectors, so the sector is a
-// plain shift of the word and the residual angle is small enough for sin(delta) = delta; and the draw
-// is the MULTIPLIER itself, fma(r std, cos theta, 100 + mean).
+// Counter stream v3: the same construction with cheaper arithmetic (9.5 instead
+// of 16.5 VALU per draw).  The distance w of the uniform from the nearer end goes to binary32 as w | 1
+// (one v_bitop3 with the XOR that forms w); the radius bin is ONE bit-field of the float -- the
+// octaves are stored rotated -- with the side OR-ed in above it; the cubic's argument is the float the
+// OR of the low mantissa bits into 1.0f leaves (the coefficients carry the shift to the bin's middle);
+// the angle table has 2048 entries at the MIDDLE of their sectors, so the sector is a plain shift of
+// the word, and the residual angle -- low bits OR-ed into 1.0f, one fma, no conversion -- is small
+// enough for a first-order rotation (c - s delta, s + c delta) (the table carries the factor that
+// keeps the mean square length 1); and the draw is the MULTIPLIER itself, fma(r std, cos theta, 100 +
+// mean).
 struct Bm3Pending {
   float4 kr;
   float2 cs;
-  float x, delta, cd;
+  float y, delta;
 };
 
 // A load from an LDS byte address held in a register.  The v3 tables sit at LDS address 0 (the
@@ -200,31 +226,34 @@ __device__ __forceinline__ T lds_load_at(uint32_t byte_addr) {
 
 __device__ __forceinline__ Bm3Pending bm3_issue(const float *lds_bm, uint32_t ua, uint32_t ub) {
   Bm3Pending p;
+  constexpr uint32_t kLow = 23u - kBm3SubBits;                 // mantissa bits below the sub-interval
+  constexpr uint32_t kSide = (32u << kBm3SubBits) * 16u;       // bytes of one side of the radius table
   const uint32_t mask = static_cast<uint32_t>(static_cast<int32_t>(ua) >> 31);  // all ones when U >= 1/2
   const uint32_t w1 = __builtin_amdgcn_bitop3_b32(ua, mask, 1u, 0xbe);           // (ua ^ mask) | 1: (0xf0 ^ 0xcc) | 0xaa
   const uint32_t bits = __float_as_uint(static_cast<float>(w1));                 // exponent 127 .. 158
-  // byte offset of the bin's four coefficients: ((bits >> 19) & 511) * 16 | side * 512 * 16
-  const uint32_t off = ((bits >> 15) & 0x1ff0u) | (mask & 0x2000u);
-  p.x = __uint_as_float((bits & 0x0007ffffu) | 0x3f800000u) - 1.03125f;
+  // byte offset of the bin's four coefficients: (exponent low 5 bits : sub-interval) * 16 | side
+  const uint32_t off = ((bits >> (kLow - 4u)) & (kSide - 16u)) | (mask & kSide);
+  p.y = __uint_as_float((bits & ((1u << kLow) - 1u)) | 0x3f800000u);
   (void)lds_bm;
   const f32x4_t kr = lds_load_at<f32x4_t>(off);
   p.kr = make_float4(kr.x, kr.y, kr.z, kr.w);
 
-  const uint32_t aoff = (ub >> 20) & 0xff8u;               // (ub >> 23) * 8: the sector, no rounding add
-  // residual angle from the sector's middle: (low 23 bits - 2^22) 2 pi / 2^32, one fma (exactly 0 at
-  // the middle: 2^22 C and pi/512 share their binary32 mantissa)
-  p.delta = __builtin_fmaf(static_cast<float>(ub & 0x007fffffu), 0x1.921fb6p-30f, -0x1.921fb6p-8f);
-  p.cd = __builtin_fmaf(p.delta * p.delta, -0.5f, 1.0f);
+  constexpr uint32_t kRes = 32u - kBm3TrigBits;                // residual bits below the sector
+  const uint32_t aoff = (ub >> (kRes - 3u)) & ((kBm3TrigEntries - 1u) << 3);  // sector * 8, no rounding add
+  // residual angle from the sector's middle, (low bits - half a sector) 2 pi / 2^32: the low bits as the
+  // mantissa of a float in [1, 1 + 2^-(TRIG_BITS - 9)), then one fma
+  const float ya = __uint_as_float((ub & ((1u << kRes) - 1u)) | 0x3f800000u);
+  p.delta = __builtin_fmaf(ya, kBm3AngleK, -kBm3AngleC);
   const f32x2_t cs = lds_load_at<f32x2_t>(aoff + kBm3RadiusEntries * 16u);
   p.cs = make_float2(cs.x, cs.y);
   return p;
 }
 
-__device__ __forceinline__ void bm3_finish(const Bm3Pending &p, float scale, float shift, float &d_cos, float &d_sin) {
-  const float r = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(p.kr.w, p.x, p.kr.z), p.x, p.kr.y), p.x, p.kr.x);
-  const float rs = r * scale;
-  const float ct = __builtin_fmaf(-p.cs.y, p.delta, p.cs.x * p.cd);
-  const float st = __builtin_fmaf(p.cs.x, p.delta, p.cs.y * p.cd);
+// The staged radius coefficients carry the factor std (stage_tables): the cubic IS r std.
+__device__ __forceinline__ void bm3_finish(const Bm3Pending &p, float shift, float &d_cos, float &d_sin) {
+  const float rs = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(p.kr.w, p.y, p.kr.z), p.y, p.kr.y), p.y, p.kr.x);
+  const float ct = __builtin_fmaf(-p.cs.y, p.delta, p.cs.x);
+  const float st = __builtin_fmaf(p.cs.x, p.delta, p.cs.y);
   d_cos = __builtin_fmaf(rs, ct, shift);
   d_sin = __builtin_fmaf(rs, st, shift);
 }
@@ -237,7 +266,18 @@ __device__ __forceinline__ void stage_tables(const KernelArgs &k, float *lds, ui
   } else {
     const float4 *src = reinterpret_cast<const float4 *>(k.bm_tables);
     float4 *dst = reinterpret_cast<float4 *>(lds);
-    for (uint32_t i = threadIdx.x; i < bm_floats(kMode) / 4; i += block) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < bm_floats(kMode) / 4; i += block) {
+      float4 v = src[i];
+      if (kMode == SMMC_MODE_GAUSSIAN && i < kBm3RadiusEntries) {
+        // counter stream v3: each radius coefficient times std, rounded once -- the cubic then yields
+        // r std and the draw needs no multiply of its own
+        v.x *= k.gauss_std;
+        v.y *= k.gauss_std;
+        v.z *= k.gauss_std;
+        v.w *= k.gauss_std;
+      }
+      dst[i] = v;
+    }
   }
 }
 
@@ -263,12 +303,12 @@ __device__ __forceinline__ void digits4(uint32_t h, uint32_t l, uint32_t T, uint
 }
 
 // The per-period multipliers a = 100.0f + r of Philox block `blk` of a path.
-template <int kMode, bool kDense>
+template <int kMode, bool kDense, bool kUniformBlock = false>
 __device__ __forceinline__ void block_multipliers(const KernelArgs &k, const float *lds_table,
                                                   uint32_t path_lo, uint32_t path_hi, uint32_t blk,
                                                   float (&a)[Draws<kMode, kDense>::value]) {
   uint32_t u[4];
-  philox4x32_10(path_lo, path_hi, blk, mode_tag(kMode), k.key0, k.key1, u);
+  philox4x32_10<kUniformBlock>(path_lo, path_hi, blk, mode_tag(kMode), k.key0, k.key1, u);
   if constexpr (kMode == SMMC_MODE_TABLE && kDense) {
     uint32_t ia[4], ib[4];
     digits4(u[0], u[1], k.table_len, ia);
@@ -290,15 +330,15 @@ __device__ __forceinline__ void block_multipliers(const KernelArgs &k, const flo
   } else {  // counter stream v3: the multipliers themselves, N(100 + gauss_mean, gauss_std)
     const Bm3Pending p0 = bm3_issue(lds_table, u[0], u[1]);
     const Bm3Pending p1 = bm3_issue(lds_table, u[2], u[3]);
-    bm3_finish(p0, k.gauss_std, k.gauss_shift100, a[0], a[1]);
-    bm3_finish(p1, k.gauss_std, k.gauss_shift100, a[2], a[3]);
+    bm3_finish(p0, k.gauss_shift100, a[0], a[1]);
+    bm3_finish(p1, k.gauss_shift100, a[2], a[3]);
   }
 }
 
 // The multipliers of the N consecutive Philox blocks blk .. blk + N - 1 of a path, drawn TOGETHER:
 // interleaved Philox rounds, then all table gathers issued before the first is used.  The values are
 // those of N calls of block_multipliers.
-template <int kMode, bool kDense, int N>
+template <int kMode, bool kDense, int N, bool kUniformBlock = false>
 __device__ __forceinline__ void block_multipliers_multi(const KernelArgs &k, const float *lds_table, uint32_t path_lo,
                                                         uint32_t path_hi, uint32_t blk,
                                                         float (&a)[N][Draws<kMode, kDense>::value]) {
@@ -310,7 +350,7 @@ __device__ __forceinline__ void block_multipliers_multi(const KernelArgs &k, con
     u[i][2] = blk + i;
     u[i][3] = mode_tag(kMode);
   }
-  philox4x32_10_multi<N>(u, k.key0, k.key1);
+  philox4x32_10_multi<N, kUniformBlock>(u, k.key0, k.key1);
   if constexpr (kMode == SMMC_MODE_TABLE && kDense) {
     uint32_t idx[N][8];
 #pragma unroll
@@ -357,8 +397,8 @@ __device__ __forceinline__ void block_multipliers_multi(const KernelArgs &k, con
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      bm3_finish(p[i][0], k.gauss_std, k.gauss_shift100, a[i][0], a[i][1]);
-      bm3_finish(p[i][1], k.gauss_std, k.gauss_shift100, a[i][2], a[i][3]);
+      bm3_finish(p[i][0], k.gauss_shift100, a[i][0], a[i][1]);
+      bm3_finish(p[i][1], k.gauss_shift100, a[i][2], a[i][3]);
     }
   }
 }
@@ -388,7 +428,7 @@ __device__ __forceinline__ float simulate_path(const KernelArgs &k, const float 
   // front of this block's chain.)
   for (uint32_t blk = 0; blk < full; ++blk) {
     float a[kDraws];
-    block_multipliers<kMode, kDense>(k, lds_table, path_lo, path_hi, blk, a);
+    block_multipliers<kMode, kDense, true>(k, lds_table, path_lo, path_hi, blk, a);
 #pragma unroll
     for (int j = 0; j < kDraws; ++j) total = compound<kExactDiv>(total, a[j]);
     if constexpr (kDiv == kDivChecked) left_window |= !(total > k.chk_lo && total < k.chk_hi);  // NaN leaves too
@@ -396,7 +436,7 @@ __device__ __forceinline__ float simulate_path(const KernelArgs &k, const float 
   const uint32_t rem = k.n_periods - full * kDraws;
   if (rem) {  // wave-uniform
     float a[kDraws];
-    block_multipliers<kMode, kDense>(k, lds_table, path_lo, path_hi, full, a);
+    block_multipliers<kMode, kDense, true>(k, lds_table, path_lo, path_hi, full, a);
 #pragma unroll
     for (int j = 0; j < kDraws - 1; ++j)
       if (static_cast<uint32_t>(j) < rem) total = compound<kExactDiv>(total, a[j]);
@@ -1057,7 +1097,7 @@ __global__ __launch_bounds__(kCombMaxBlock) void keepdata_comb_kernel(const Kern
       // their compounding chains follow one after the other.  The host guarantees that a row is a
       // whole number of steps.
       float a[kBlocksPerStep][kDraws];
-      block_multipliers_multi<kMode, kDense, kBlocksPerStep>(k, lds_table, path_lo, path_hi, blk, a);
+      block_multipliers_multi<kMode, kDense, kBlocksPerStep, true>(k, lds_table, path_lo, path_hi, blk, a);
 #pragma unroll
       for (int b = 0; b < kBlocksPerStep; ++b) {
         if (done) break;

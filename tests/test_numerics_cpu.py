@@ -38,7 +38,7 @@ def test_box_muller_tables_identical_in_oracle_and_product():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     a = open(os.path.join(root, "oracle", "smmc_bm_tables.inc")).read()
     b = open(os.path.join(root, "stock_market_monte_carlo_amd", "csrc", "smmc_bm_tables.inc")).read()
-    assert a == b and "SMMC_BM_RADIUS_ENTRIES 1056" in a and "SMMC_BM3_RADIUS_ENTRIES 1024" in a
+    assert a == b and "SMMC_BM_RADIUS_ENTRIES 1056" in a and "SMMC_BM3_RADIUS_ENTRIES 512" in a and "SMMC_BM3_TRIG_ENTRIES 2048" in a
 
 
 def test_box_muller_moments_and_accuracy(oracle):
@@ -68,8 +68,10 @@ def test_box_muller_moments_and_accuracy(oracle):
 
 
 def test_stream_v3_radius_table_accuracy(oracle):
-    """Counter stream v3's radius: f = fl(w | 1), u = f / 2^32 in (0, 1/2], 32 octaves stored rotated so
-    that the bin is one bit-field of f, cubic in x' in [-1/32, 1/32).  Same bound as v2's table."""
+    """Counter stream v3's radius: f = fl(w | 1), u = f / 2^32 in (0, 1/2], 32 octaves of 8 sub-intervals
+    stored rotated so that the bin is one bit-field of f, cubic in y = as_float(0x3f800000 | low 20
+    mantissa bits) in [1, 1.125) with the shift to the bin's middle folded into the coefficients.  Same
+    bound as v2's table."""
     assert oracle.bm3_radius_scan(0, 2 ** 32, 499) < 6e-7
     assert oracle.bm3_radius_scan(0, 1 << 20, 1) < 6e-7                       # deepest tail, every value
     assert oracle.bm3_radius_scan((1 << 32) - (1 << 20), 1 << 32, 1) < 6e-7  # U -> 1 end (sqrt singularity)
@@ -88,6 +90,10 @@ def test_stream_v3_radius_table_accuracy(oracle):
 
 
 def test_stream_v3_box_muller_moments_and_accuracy(oracle):
+    """v3 rotates the table's (cos, sin) by the residual angle to FIRST order: the draw is r cos(theta)
+    times sqrt(1 + delta^2) kappa, a factor within -3.9e-7 .. +7.8e-7 of 1 whose mean square is 1, at an
+    angle off by delta^3/3 <= 1.2e-9.  Checked here: against the exact r cos / sin relative to 1 + r,
+    the length factor's range and mean square, and the moments."""
     rng = np.random.default_rng(5)
     ua = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64)
     ub = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64)
@@ -96,31 +102,47 @@ def test_stream_v3_box_muller_moments_and_accuracy(oracle):
     u = ((ua ^ mask) | np.uint64(1)).astype(np.float32).astype(np.float64) / 2.0 ** 32
     r = np.where(ua >> 31, np.sqrt(-2 * np.log1p(-u)), np.sqrt(-2 * np.log(u)))
     th = 2 * np.pi * ub.astype(np.float64) / 2.0 ** 32
-    # |dz|: radius table 4.1e-7 + sin(delta) = delta (3.9e-8 x r) + binary32 roundings
-    assert np.abs(z[:, 0] - r * np.cos(th)).max() < 1.2e-6
-    assert np.abs(z[:, 1] - r * np.sin(th)).max() < 1.2e-6
+    # |dz|: radius table 5.5e-7 + length factor 7.8e-7 r + binary32 roundings
+    assert (np.abs(z[:, 0] - r * np.cos(th)) / (1 + r)).max() < 1.0e-6
+    assert (np.abs(z[:, 1] - r * np.sin(th)) / (1 + r)).max() < 1.0e-6
+    assert np.abs(z[:, 0] - r * np.cos(th)).max() < 5e-6 and np.abs(z[:, 1] - r * np.sin(th)).max() < 5e-6
+    # without the length factor (the first-order rotation evaluated in double) what is left is the
+    # radius table and roundings: the same 1.2e-6 as a second-order rotation gave
+    n_sec = 2048
+    dmax = np.pi / n_sec
+    delta = th - 2 * np.pi * ((ub >> np.uint64(21)).astype(np.float64) + 0.5) / n_sec
+    assert np.abs(delta).max() <= dmax * (1 + 1e-12)
+    factor = np.sqrt(1 + delta ** 2) / np.sqrt(1 + dmax ** 2 / 3)
+    th1 = th - delta + np.arctan(delta)
+    assert np.abs(z[:, 0] - factor * r * np.cos(th1)).max() < 1.2e-6
+    assert np.abs(z[:, 1] - factor * r * np.sin(th1)).max() < 1.2e-6
+    assert factor.min() > 1 - 3.95e-7 and factor.max() < 1 + 7.9e-7 and abs((factor ** 2).mean() - 1) < 2e-8
+    big = r > 0.5
+    length = np.hypot(z[big, 0], z[big, 1]) / r[big]
+    assert abs((length ** 2).mean() - 1) < 5e-8          # no net scale: the variance of the draws is kept
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
     # the scaled form: the kernels draw the MULTIPLIER fma(r std, cos, 100 + mean)
     zc, zs = oracle.box_muller3(123456789, 987654321)
     dc, ds = oracle.box_muller3_scaled(123456789, 987654321, 0.83333, 100.5)
     assert dc == pytest.approx(100.5 + 0.83333 * zc, abs=1e-5) and ds == pytest.approx(100.5 + 0.83333 * zs, abs=1e-5)
     for a, b in [(0, 0), (0xFFFFFFFF, 0xFFFFFFFF), (0, 0x80000000), (0xFFFFFFFF, 0x40000000), (1, 0x3FFFFFFF),
-                 (0x7FFFFFFF, 0x003FFFFF), (0x80000000, 0x00400000), (0x12345678, 0xFFC00000), (5, 0xFFFFFFFF)]:
+                 (0x7FFFFFFF, 0x001FFFFF), (0x80000000, 0x00200000), (0x12345678, 0xFFE00000), (5, 0xFFFFFFFF)]:
         zc, zs = oracle.box_muller3(a, b)
         assert np.isfinite(zc) and np.isfinite(zs) and abs(zc) < 7 and abs(zs) < 7
         assert abs(np.hypot(zc, zs) - oracle.bm3_radius(a)) < 1e-5 * (1 + oracle.bm3_radius(a))
-    # the table angles are sector middles, so nothing is exact at the axes, only within rounding;
-    # the middle of a sector has delta == 0 exactly and returns the table entry itself
-    zc, zs = oracle.box_muller3(0, 0)
-    assert zc == pytest.approx(oracle.bm3_radius(0), rel=2e-7) and abs(zs) < 1e-6
-    zc, zs = oracle.box_muller3(0, 0x40000000)
-    assert abs(zc) < 1e-6 and zs == pytest.approx(oracle.bm3_radius(0), rel=2e-7)
-    zc, zs = oracle.box_muller3(0, 0xFFFFFFFF)  # 2 pi - epsilon: last sector, upper edge
-    assert zc == pytest.approx(oracle.bm3_radius(0), rel=2e-7) and abs(zs) < 1e-6
-    zc, zs = oracle.box_muller3(0, (37 << 23) | (1 << 22))
+    # the table angles are sector middles, so nothing is exact at the axes, only within rounding and the
+    # length factor; at the middle of a sector delta is 0 to within 1e-9 and the table entry comes back
     r0 = oracle.bm3_radius(0)
-    assert zc == float(np.float32(r0) * np.float32(np.cos(2 * np.pi * 37.5 / 512)))
-    assert zs == float(np.float32(r0) * np.float32(np.sin(2 * np.pi * 37.5 / 512)))
+    zc, zs = oracle.box_muller3(0, 0)
+    assert zc == pytest.approx(r0, rel=1e-6) and abs(zs) < 1e-5
+    zc, zs = oracle.box_muller3(0, 0x40000000)
+    assert abs(zc) < 1e-5 and zs == pytest.approx(r0, rel=1e-6)
+    zc, zs = oracle.box_muller3(0, 0xFFFFFFFF)  # 2 pi - epsilon: last sector, upper edge
+    assert zc == pytest.approx(r0, rel=1e-6) and abs(zs) < 1e-5
+    zc, zs = oracle.box_muller3(0, (37 << 21) | (1 << 20))
+    kappa = 1 / np.sqrt(1 + dmax ** 2 / 3)
+    assert zc == pytest.approx(r0 * kappa * np.cos(2 * np.pi * 37.5 / n_sec), rel=3e-7)
+    assert zs == pytest.approx(r0 * kappa * np.sin(2 * np.pi * 37.5 / n_sec), rel=3e-7)
 
 
 def test_stream_v3_return_is_the_multiplier_minus_100(oracle, table):

@@ -46,41 +46,57 @@ def fit_bin(side, c, j):
 
 # ---- counter stream v3 -------------------------------------------------------------------------
 # radius: f = fl(w | 1), w the 31-bit distance of the uniform from the nearer end of (0, 1), u = f / 2^32
-# in (0, 1/2].  Exponent 127 .. 158: 32 octaves; table index = (bits >> 19) & 511 = (exponent << 4 | sub)
-# & 511, i.e. the octaves are stored rotated (exponent 128 first, exponent 127 last) so that the index is
-# one bit-field extract; side 1 (distance from 1) follows at +512.  The cubic's argument is
-# x' = as_float(0x3f800000 | low 19 mantissa bits) - (1 + 1/32), in [-1/32, 1/32): no shift needed.
+# in (0, 1/2].  Exponent 127 .. 158: 32 octaves of 2^SUB3_BITS sub-intervals; table index =
+# (bits >> (23 - SUB3_BITS)) & (32 << SUB3_BITS) - 1 = (exponent << SUB3_BITS | sub) masked, i.e. the
+# octaves are stored rotated (exponent 128 first, exponent 127 last) so that the index is one bit-field
+# extract; side 1 (distance from 1) follows.  The cubic is in y = as_float(0x3f800000 | low mantissa
+# bits), in [1, 1 + 2^-SUB3_BITS), AS IT COMES OUT OF THE OR: the shift to the bin's middle is folded
+# into the coefficients (composition in double, one rounding to binary32).
+# angle: 2^TRIG3_BITS sectors, (cos, sin) at the MIDDLE of each, multiplied by kappa = 1 / sqrt(1 +
+# dmax^2 / 3), dmax = pi / 2^TRIG3_BITS: the kernels rotate by the residual angle delta to FIRST order,
+# (c - s delta, s + c delta), a vector of length sqrt(1 + delta^2); kappa makes its mean square 1.
 OCT3 = 32
+SUB3_BITS = 3
+TRIG3_BITS = 11
+SUB3 = 1 << SUB3_BITS
 
 
 def fit_bin3(side, c, j):
     nodes = 0.5 * np.cos(np.pi * (np.arange(64) + 0.5) / 64)  # Chebyshev nodes in [-0.5, 0.5]
-    u = 2.0 ** (c - 32) * (1.0 + (j + 0.5 + nodes) / SUB)
+    u = 2.0 ** (c - 32) * (1.0 + (j + 0.5 + nodes) / SUB3)
     coef = Ch.chebfit(nodes * 2.0, radius(u, side), 3)          # T_k(2x), x in [-0.5, 0.5]
     p = Ch.cheb2poly(coef)
     p = np.array([p[k] * 2.0 ** k for k in range(4)])           # power basis in x
-    p = np.array([p[k] * 16.0 ** k for k in range(4)])          # power basis in x' = x / 16
-    p32 = p.astype(np.float32)
-    xs = np.linspace(-0.5, 0.5, 257)
-    us = 2.0 ** (c - 32) * (1.0 + (j + 0.5 + xs) / SUB)
-    err = np.abs(Po.polyval(xs / 16.0, p32.astype(np.float64)) - radius(us, side)).max()
-    return p32, err
+    # x = SUB3 (y - 1) - 0.5: compose
+    q = np.zeros(4)
+    lin = np.array([-SUB3 - 0.5, float(SUB3)])                  # x as a polynomial in y
+    acc = np.array([1.0])
+    for k in range(4):
+        q[:len(acc)] += p[k] * acc
+        acc = Po.polymul(acc, lin)
+    q32 = q.astype(np.float32)
+    ys = 1.0 + np.linspace(0.0, 1.0, 257) / SUB3
+    us = 2.0 ** (c - 32) * (1.0 + (j + (ys - 1.0) * SUB3) / SUB3)
+    err = np.abs(Po.polyval(ys, q32.astype(np.float64)) - radius(us, side)).max()
+    return q32, err
 
 
 def v3_tables():
     rows, worst = [], 0.0
     for side in (0, 1):
-        for t in range(OCT3 * SUB):           # table index within the side
-            e = 128 + (t >> 4) if (t >> 4) < 31 else 127   # exponent stored at this index
-            c, j = e - 127, t & 15
-            # octave 31 (exponent 158) holds the single value f = 2^31 (u = 1/2, sub 0, x' = -1/32): its
+        for t in range(OCT3 * SUB3):           # table index within the side
+            o = t >> SUB3_BITS
+            e = 128 + o if o < 31 else 127     # exponent stored at this index
+            c, j = e - 127, t & (SUB3 - 1)
+            # octave 31 (exponent 158) holds the single value f = 2^31 (u = 1/2, sub 0, y = 1): its
             # other sub-intervals are never read and repeat sub-interval 0
             p, err = fit_bin3(side, c, 0 if c == OCT3 - 1 else j)
             worst = max(worst, err)
             rows.append(p)
-    # angles at the MIDDLE of each of the 512 sectors: the index is then ub >> 23 with no rounding add,
-    # and the residual angle (low 23 bits - 2^22) 2 pi / 2^32 lies in [-pi/512, pi/512)
-    trig = [(np.cos(2 * np.pi * (i + 0.5) / 512), np.sin(2 * np.pi * (i + 0.5) / 512)) for i in range(512)]
+    n = 1 << TRIG3_BITS
+    dmax = np.pi / n
+    kappa = 1.0 / np.sqrt(1.0 + dmax * dmax / 3.0)
+    trig = [(kappa * np.cos(2 * np.pi * (i + 0.5) / n), kappa * np.sin(2 * np.pi * (i + 0.5) / n)) for i in range(n)]
     return rows, trig, worst
 
 
@@ -115,18 +131,24 @@ def main():
         out.append("  {" + hexf(c) + ", " + hexf(s) + "},")
     out.append("};")
     rows3, trig3, worst3 = v3_tables()
-    out += ["// counter stream v3: radius [side][(exponent << 4 | sub) & 511] x {c0..c3} in x' (see tools/gen_bm_tables.py); "
-            f"max fit error {worst3:.3g}",
+    k32 = np.float32(2 * np.pi / 512)
+    c32 = np.float32(float(k32) * (1.0 + 2.0 ** (8 - TRIG3_BITS)))
+    out += ["// counter stream v3: radius [side][(exponent << SUB_BITS | sub) masked] x {q0..q3}, r = q0 + y (q1 + y (q2 + y q3)), "
+            f"y in [1, 1 + 2^-SUB_BITS) (see tools/gen_bm_tables.py); max fit error {worst3:.3g}",
+            "// trig: (cos, sin) of the sector middles x kappa; residual angle delta = fma(y, ANGLE_K, -ANGLE_C),",
+            "// y = as_float(0x3f800000 | low (32 - TRIG_BITS) bits of the word)",
+            "#define SMMC_BM3_SUB_BITS %d" % SUB3_BITS,
+            "#define SMMC_BM3_TRIG_BITS %d" % TRIG3_BITS,
+            "#define SMMC_BM3_ANGLE_K %s" % hexf(k32),
+            "#define SMMC_BM3_ANGLE_C %s" % hexf(c32),
             "#define SMMC_BM3_RADIUS_ENTRIES %d" % len(rows3),
-            "#define SMMC_BM3_TRIG_ENTRIES 512",
+            "#define SMMC_BM3_TRIG_ENTRIES %d" % len(trig3),
             "static const float smmc_bm3_radius[SMMC_BM3_RADIUS_ENTRIES][4] = {"]
     for p in rows3:
         out.append("  {" + ", ".join(hexf(v) for v in p) + "},")
     out.append("};")
     out.append("static const float smmc_bm3_trig[SMMC_BM3_TRIG_ENTRIES][2] = {")
     for c, s in trig3:
-        c = 0.0 if abs(c) < 1e-15 else c
-        s = 0.0 if abs(s) < 1e-15 else s
         out.append("  {" + hexf(c) + ", " + hexf(s) + "},")
     out.append("};")
     text = "\n".join(out) + "\n"
