@@ -518,16 +518,14 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     a.n_paths = n_comb;
     const int waves = comb_waves;
     // rows per stream.  More rows cost fewer extra columns (4.3 % at K = 1, 2.1 % at K = 2 for P = 360)
-    // but make the chunks a wave takes coarser.  Measured (tools/kd_ab.py, stream v3): Gaussian, where
-    // the columns cost arithmetic, 4e6 x 361: K = 2 1.198 ms, K = 1 1.214; 1.5e6 x 1001 (3 chunks per
-    // wave at K = 2): K = 1 1.339 ms, K = 2 1.412.  Table mode, bound by the stores: K = 1.
+    // but make the chunks a wave takes coarser.  Measured (tools/kd_ab.py, profiles/r02/keepdata_ab_stream_v3.txt):
+    // Gaussian 4e6 x 361: K = 1 1.141 ms, K = 2 1.150, K = 4 1.159; 1.5e6 x 1001: 1.293 / 1.324 / 1.344;
+    // table mode 1.095 / 1.103 and 1.212 / 1.236.  (With the costlier draws of stream v2 K = 2 won the
+    // first shape by 1.3 %.)
     uint32_t k_rows = 1;
-    if (sim->mode == SMMC_MODE_GAUSSIAN && n_super * 16u >= 8ull * e->compute_units * static_cast<uint64_t>(waves)) k_rows = 2;
     if (const char *env = std::getenv("SMMC_KEEPDATA_K")) {  // tuning knob: 1, 2, 4, 8, 16 or 32
       const long v = std::strtol(env, nullptr, 10);
       if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k_rows = static_cast<uint32_t>(v);
-    } else {
-      while (k_rows > 1 && n_super * (32u / k_rows) < 4ull * e->compute_units * static_cast<uint64_t>(waves)) k_rows /= 2;
     }
     const uint64_t n_wave_chunks = n_super * (32u / k_rows);
     const uint32_t per_cu = e->keepdata_blocks_per_cu ? e->keepdata_blocks_per_cu : 1u;
