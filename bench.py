@@ -334,6 +334,10 @@ def main():
                     help="all = final values + block means + statistics (configs[1]); final = final values only; "
                          "stats = statistics only (no per-path HBM write); host = final values into pinned host "
                          "memory through the chunked side-stream pipeline (configs[4])")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="with --gpus 1: still initialise the process group (one rank) and run every collective "
+                         "of the N > 1 path -- barrier, the record all_gather, the max-reduce of the time -- so that "
+                         "a one-GPU box exercises torch's nccl backend (RCCL)")
     ap.add_argument("--launch-check", action="store_true",
                     help="CPU-only rehearsal of rank launch + rendezvous + the statistics gather (no GPU work)")
     args = ap.parse_args()
@@ -379,7 +383,12 @@ def main():
                          "(use --backend gloo to rehearse several ranks on one GPU)")
     device = local_rank % n_dev
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dist = world > 1 or args.rehearse_rccl
+    if use_dist:
+        if world == 1 and not have_ranks:
+            for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"),
+                             ("MASTER_PORT", str(_free_port()))):
+                os.environ.setdefault(key, val)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -419,11 +428,11 @@ def main():
             return None
         r = eng.simulate(sim, want_final=want_final, want_chunk_stats=want_chunks, want_stats=want_stats, out=final)
         if want_stats:
-            records = gather_stats_records(r.stats_raw) if world > 1 else None
+            records = gather_stats_records(r.stats_raw, force=use_dist) if use_dist else None
         return r
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -442,7 +451,7 @@ def main():
 
     devices = [None] * world
     mine = f"rank {rank}: cuda:{device} {torch.cuda.get_device_name(device)}"
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.tdevice if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -459,7 +468,7 @@ def main():
 
     stats = None
     if want_stats and last is not None:
-        if world > 1:
+        if use_dist:
             stats = stats_from_bytes(merge_stats_bytes(records))
         else:
             stats = eng.read_stats(last.stats_raw)
@@ -494,8 +503,8 @@ def main():
         out = {
             "metric": "simulated paths/sec at N=360 periods" if periods == 360
                       else f"simulated paths/sec at N={periods} periods",
-            "value": value, "unit": "paths/s", "n_gpus": world, "ranks": dist.get_world_size() if world > 1 else 1,
-            "backend": ("rccl (torch nccl)" if args.backend == "nccl" else "gloo") if world > 1 else "none",
+            "value": value, "unit": "paths/s", "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
+            "backend": ("rccl (torch nccl)" if args.backend == "nccl" else "gloo") if use_dist else "none",
             "devices": devices, "launcher": "self" if os.environ.get("SMMC_BENCH_CHILD") else
                                             ("external" if have_ranks else "none"),
             "steps": args.steps, "warmup": args.warmup,
@@ -527,7 +536,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(table)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -24,14 +24,15 @@ def shard_range(n_total, world, rank):
     return first, count
 
 
-def gather_stats_records(record, group=None):
+def gather_stats_records(record, group=None, force=False):
     """record: uint8 tensor holding this rank's packed statistics record (device tensor
     under nccl, CPU tensor under gloo).  Returns the list of all ranks' records as bytes,
-    in rank order.  One all_gather."""
+    in rank order.  One all_gather (skipped for a one-rank group unless `force`: a one-GPU
+    rehearsal of the collective, bench.py --rehearse-rccl)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return [record.cpu().numpy().tobytes()]
     if dist.get_backend(group) == "gloo" and record.is_cuda:
         record = record.cpu()  # gloo (CPU rehearsals of the N > 1 path) gathers host tensors

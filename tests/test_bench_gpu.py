@@ -1,0 +1,48 @@
+"""bench.py on the GPU box, as child processes (a test process that has initialised the GPU must not
+exec; it may start children): the line the driver parses, and the collectives of the N > 1 path run
+through torch's nccl backend (RCCL) with the one rank a one-GPU box can give it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*flags, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, BENCH, *flags], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_carries_the_contract_fields():
+    d = _run("--steps", "2", "--warmup", "1", "--paths-per-gpu", "4000000", "--no-cpu-baseline")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["ranks"] == 1 and d["backend"] == "none" and d["unit"] == "paths/s"
+    assert d["value"] == pytest.approx(4000000 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.001  # HIP-event kernel time fits inside the step
+    assert d["result"]["hist_total"] == 4000000
+    assert 0 < d["valu"]["frac"] < 1
+
+
+def test_rccl_collectives_of_the_multi_rank_path_run_with_one_rank():
+    """--rehearse-rccl: the process group is really initialised with backend nccl (= RCCL on ROCm) and the
+    step's all_gather of the 864-byte statistics record, the barriers and the max-reduce of the time go
+    through it; the merged record must be the rank's own."""
+    d = _run("--rehearse-rccl", "--config", "3", "--total-paths", "3000001", "--steps", "2", "--warmup", "1",
+             "--no-cpu-baseline")
+    assert d["ranks"] == 1 and d["backend"].startswith("rccl") and d["n_gpus"] == 1
+    assert d["result"]["hist_total"] == 3000001
+    plain = _run("--config", "3", "--total-paths", "3000001", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert plain["result"] == d["result"]  # gathered and merged == read directly

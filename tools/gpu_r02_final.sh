@@ -36,6 +36,7 @@ timeout -k 10 300 python bench.py --config 3 --total-paths 125000000 --steps 5 -
 timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --steps 5 --warmup 1 > $OUT/bench_gpus2_gloo.json 2> $OUT/bench_gpus2_gloo.err; echo "gpus2 rc=$?"
 timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --config 3 --steps 3 --warmup 1 > $OUT/bench_gpus2_gloo_config3.json 2> $OUT/bench_gpus2_gloo_config3.err; echo "gpus2 c3 rc=$?"
 timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --config 4 --total-paths 250000000 --steps 2 --warmup 1 > $OUT/bench_gpus2_gloo_config4.json 2> $OUT/bench_gpus2_gloo_config4.err; echo "gpus2 c4 rc=$?"
+timeout -k 10 300 python3 bench.py --rehearse-rccl --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_rehearse_rccl.json 2> $OUT/bench_rehearse_rccl.err; echo "rehearse rccl rc=$?"
 timeout -k 10 300 python tools/bench_keepdata.py > $OUT/bench_keepdata.jsonl 2> /dev/null; echo "keepdata rc=$?"
 PROF_TAG=prof_r02f bash tools/profile_r02.sh 2>&1 | tail -3
 python - <<'PY'
