@@ -536,25 +536,39 @@ ORC_API void orc_chunk_mean_var(const float *values, uint64_t n, uint32_t chunk,
 /* Checks used by tests for device-side shortcuts                             */
 /* ------------------------------------------------------------------------- */
 
-/* The HIP kernels divide by 100 with q = x*c; e = fma(-100, q, x); q' = fma(e, c, q)
- * (c = fl(1/100)).  Counts the binary32 patterns in [bits_lo, bits_hi) for which
- * that differs from the IEEE quotient x / 100.0f; first mismatch is stored. */
-ORC_API uint64_t orc_div100_mismatches(uint32_t bits_lo, uint32_t bits_hi, uint32_t *first_bad) {
-  const float c = 0.01f;
+/* The HIP kernels divide by 100 with  fma(x, ch, fl(x * cl)),  ch = fl(1/100), cl = fl(1/100 - ch)
+ * (two instructions; Brisebarre-Muller multiplication by a two-word constant).  Counts the binary32
+ * patterns in [bits_lo, bits_hi) for which that differs from the IEEE quotient x / 100.0f; the first
+ * mismatch is stored.  form = 3 counts round 1's three-instruction form instead
+ * (q = x ch; e = fma(-100, q, x); fma(e, ch, q)). */
+ORC_API uint64_t orc_div100_mismatches_form(uint32_t bits_lo, uint32_t bits_hi, uint32_t *first_bad, int form) {
+  const float ch = 0.01f, cl = 0x1.eb851ep-33f;
   uint64_t bad = 0;
   for (uint64_t b = bits_lo; b < bits_hi; b++) {
     float x = u2f((uint32_t)b);
-    float q = x * c;
-    float e = fmaf(-100.0f, q, x);
-    float q2 = fmaf(e, c, q);
+    float got;
+    if (form == 3) {
+      float q = x * ch;
+      float e = fmaf(-100.0f, q, x);
+      got = fmaf(e, ch, q);
+    } else {
+      got = fmaf(x, ch, x * cl);
+    }
     float ref = x / 100.0f;
-    if (f2u(q2) != f2u(ref)) {
+    if (f2u(got) != f2u(ref)) {
       if (!bad && first_bad) *first_bad = (uint32_t)b;
       bad++;
     }
   }
   return bad;
 }
+
+ORC_API uint64_t orc_div100_mismatches(uint32_t bits_lo, uint32_t bits_hi, uint32_t *first_bad) {
+  return orc_div100_mismatches_form(bits_lo, bits_hi, first_bad, 2);
+}
+
+/* cl as the kernels spell it: fl(1/100 - fl(1/100)) */
+ORC_API float orc_div100_cl(void) { return (float)(0.01L - (long double)0.01f); }
 
 /* Scans ua = lo, lo + stride, ... < hi: largest absolute error of orc_bm_radius against
  * sqrt(-2 ln((2 ua + 1) / 2^33)) in double precision. */

@@ -135,8 +135,9 @@ int check_sim(const smmc_engine *e, const smmc_sim *s) {
   return SMMC_OK;
 }
 
-// The reciprocal-multiply divide is exact for every finite |x| >= 2^-124 (and x = +0), x being the
-// product total * a.  Bounds on a = 100 + r for one period: false if there are none.
+// The two-instruction divide (div100, smmc_kernels.hip) is exact for every finite |x| >= 2^-114 (and
+// x = +0), x being the product total * a; the host keeps to |x| >= 2^-90, where its low product is a
+// normal number too.  Bounds on a = 100 + r for one period: false if there are none.
 bool multiplier_bounds(const smmc_engine *e, const smmc_sim *s, double *lo_a, double *hi_a) {
   if (s->mode == SMMC_MODE_TABLE) {
     if (!e->table_finite) return false;
@@ -153,12 +154,13 @@ bool multiplier_bounds(const smmc_engine *e, const smmc_sim *s, double *lo_a, do
 }
 
 // Which divide a launch may use (SMMC_DIV_*).  FAST: no product of any path can leave
-// [2^-123, 2^127) or change sign, proven from the bounds, the capital and the number of periods
+// [2^-89, 2^127) or change sign, proven from the bounds, the capital and the number of periods
 // (one bit of margin on each side for the roundings along the way).  CHECKED (paths_kernel only):
 // not provable -- a table with one +42 % month fails for 360 periods -- but a path inside
 // [*chk_lo, *chk_hi] at a Philox-block boundary cannot leave the domain during the next 8 periods,
 // so the kernel tests that window once per block and redoes the rare path that leaves it with the
 // IEEE divide.  EXACT otherwise, or on request.
+constexpr double kFastDivLog2Min = -89.0;  // products stay above 2^-89: one bit above the 2^-90 the divide is used from
 int divide_kind(const smmc_engine *e, const smmc_sim *s, bool allow_checked, float *chk_lo, float *chk_hi) {
   *chk_lo = 0.0f;
   *chk_hi = 0.0f;
@@ -171,11 +173,11 @@ int divide_kind(const smmc_engine *e, const smmc_sim *s, bool allow_checked, flo
   const double grow = std::max(0.0, std::log2(hi_a / 100.0)), shrink = std::max(0.0, -std::log2(lo_a / 100.0));
   const double top = std::log2(hi_a), bottom = std::min(0.0, std::log2(lo_a));
   // total after k periods lies in cap * [(lo_a/100)^k, (hi_a/100)^k]; the next product is that times a
-  if (std::log2(cap) + p * grow + top + 1.0 < 127.0 && std::log2(cap) - p * shrink + bottom - 1.0 > -123.0)
+  if (std::log2(cap) + p * grow + top + 1.0 < 127.0 && std::log2(cap) - p * shrink + bottom - 1.0 > kFastDivLog2Min)
     return SMMC_DIV_FAST;
   if (!allow_checked) return SMMC_DIV_EXACT;
   // a block is at most 8 periods: 7 steps to its last total, then one more product
-  const double hi_w = 127.0 - 1.0 - 7.0 * grow - top, lo_w = -123.0 + 1.0 + 7.0 * shrink - bottom;
+  const double hi_w = 127.0 - 1.0 - 7.0 * grow - top, lo_w = kFastDivLog2Min + 1.0 + 7.0 * shrink - bottom;
   if (!(lo_w + 2.0 < std::log2(cap) && std::log2(cap) < hi_w - 2.0)) return SMMC_DIV_EXACT;
   *chk_lo = static_cast<float>(std::exp2(lo_w));
   *chk_hi = static_cast<float>(std::exp2(hi_w));

@@ -107,19 +107,21 @@ __device__ __forceinline__ void philox4x32_10_multi(uint32_t (&c)[N][4], uint32_
   }
 }
 
-// x / 100.0f, correctly rounded.  The fast form (reciprocal multiply + one FMA
-// residual correction) equals the IEEE quotient for every binary32 x with
-// |x| >= 2^-124 (exhaustive CPU proof: tests/test_numerics_cpu.py); the host only
-// selects it when every product total * a provably stays inside [2^-123, 2^127).
+// x / 100.0f, correctly rounded, in TWO instructions: 1/100 = ch + cl with ch = fl(1/100) and
+// cl = fl(1/100 - ch); fma(x, ch, fl(x cl)) then equals the IEEE quotient for every binary32 x with
+// |x| >= 2^-114 (Brisebarre and Muller's multiplication by a constant held in two words; whether it is
+// exact for a given constant has to be checked, and for 1/100 it is: exhaustive CPU proof over all
+// 2^23 mantissas of every exponent in tests/test_numerics_cpu.py, device self-test over both signs).
+// Round 1's form -- q = x ch, one FMA for the residual, one for the correction -- took three.  The
+// host only selects it when every product total * a provably stays inside [2^-89, 2^127): there
+// x cl is a normal number as well.
 template <bool kExactDiv>
 __device__ __forceinline__ float div100(float m) {
   if constexpr (kExactDiv) {
     return m / 100.0f;  // IEEE divide (hipcc default: correctly rounded)
   } else {
-    const float c = 0.01f;
-    const float q = m * c;
-    const float e = __builtin_fmaf(-100.0f, q, m);
-    return __builtin_fmaf(e, c, q);
+    const float ch = 0.01f, cl = 0x1.eb851ep-33f;
+    return __builtin_fmaf(m, ch, m * cl);
   }
 }
 

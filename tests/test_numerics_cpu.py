@@ -11,14 +11,19 @@ def bits(f):
 
 
 def test_div100_shortcut_is_exact_on_its_whole_domain(oracle):
-    """q = x*c; e = fma(-100, q, x); q' = fma(e, c, q) equals x / 100.0f for EVERY binary32
-    with |x| >= 2^-124 (all 2.1e9 positive patterns; negatives are symmetric and covered by
-    the device self-test).  It fails only where the quotient is subnormal."""
-    bad, first = oracle.div100_mismatches(bits(2.0 ** -124), 0x7F800000)
+    """fma(x, ch, fl(x cl)) with ch = fl(1/100), cl = fl(1/100 - ch) equals x / 100.0f for EVERY binary32
+    with |x| >= 2^-114 (all positive patterns; negatives are symmetric and covered by the device
+    self-test).  It fails only where x cl loses bits to gradual underflow; the host uses it from 2^-90
+    up, where x cl is normal."""
+    import ctypes as C
+    L = oracle.lib()
+    L.orc_div100_cl.restype = C.c_float
+    assert L.orc_div100_cl() == float.fromhex("0x1.eb851ep-33")
+    bad, first = oracle.div100_mismatches(bits(2.0 ** -114), 0x7F800000)
     assert bad == 0, hex(first)
     assert oracle.div100_mismatches(0, 1)[0] == 0  # +0
     # and the documented failure region really exists (so the host-side guard is needed)
-    assert oracle.div100_mismatches(bits(2.0 ** -126), bits(2.0 ** -124))[0] > 0
+    assert oracle.div100_mismatches(bits(2.0 ** -126), bits(2.0 ** -114))[0] > 0
 
 
 def test_box_muller_radius_table_accuracy(oracle):
