@@ -148,13 +148,26 @@ constexpr uint32_t kBmFloats = kBmRadiusEntries * 4 + kBmTrigEntries * 2;
 // counter stream v3 (the default Gaussian draw): 2 x 256 radius bins (8 KiB), 2048 sectors (16 KiB)
 // (kBm3SubBits, kBm3TrigBits, kBm3AngleK, kBm3AngleC: smmc_internal.h, checked against the generated tables)
 constexpr uint32_t kBm3RadiusEntries = 64u << kBm3SubBits, kBm3TrigEntries = 1u << kBm3TrigBits;
-constexpr uint32_t kBm3Floats = kBm3RadiusEntries * 4 + kBm3TrigEntries * 2;
+constexpr uint32_t kBm3Floats = kBm3RadiusEntries * 4 + kBm3TrigEntries * 2;  // as they lie in global memory
+// ... and in LDS (stage_tables): the radius bin's byte offset is (bits >> 16) & kBm3RadiusMask of the
+// binary32 pattern of the SIGNED distance -- exponent's low five bits and three mantissa bits at
+// [4, 12), the sign (the side) left where the shift puts it, bit 15 -- so side 0 lies at [0, 4 KiB) and
+// side 1 at [32, 36 KiB); the angle table fills [4, 20 KiB) between them, [20, 32 KiB) stays unused.
+// 36 KiB per workgroup instead of 24 are four workgroups of paths_kernel per CU instead of six: the same
+// speed (measured with a padded allocation, profiles/r02/ab_lds_pad.txt; two per CU lose 17 %).
+constexpr uint32_t kBm3RadiusMask = 0x8000u | ((32u << kBm3SubBits) - 1u) << 4;
+constexpr uint32_t kBm3Side1Bytes = 0x8000u, kBm3SideBytes = (32u << kBm3SubBits) * 16u;
+constexpr uint32_t kBm3TrigBytes = kBm3SideBytes;                     // LDS byte address of the angle table
+constexpr uint32_t kBm3LdsWords = (kBm3Side1Bytes + kBm3SideBytes) / 4u;
+static_assert(kBm3TrigBytes + kBm3TrigEntries * 8u <= kBm3Side1Bytes, "angle table must fit between the radius sides");
 // The kernels' kMode template argument: SMMC_MODE_TABLE (0), SMMC_MODE_GAUSSIAN (1: counter stream
 // v3) or kModeGaussianV2 (the v2 draw, SMMC_FLAG_STREAM_V2).  The Philox counter's mode word is 1
 // for both Gaussian draws: the two streams turn the same uniforms into normals.
 constexpr int kModeGaussianV2 = 2;
 constexpr uint32_t mode_tag(int mode) { return mode == SMMC_MODE_TABLE ? 0u : 1u; }
 constexpr uint32_t bm_floats(int mode) { return mode == kModeGaussianV2 ? kBmFloats : kBm3Floats; }
+// LDS words the mode's Box-Muller tables take (what follows them starts there)
+constexpr uint32_t bm_lds_words(int mode) { return mode == kModeGaussianV2 ? kBmFloats : kBm3LdsWords; }
 
 // The two draws fma(r * scale, cos(theta), shift), fma(r * scale, sin(theta), shift), in two steps so
 // that several of them can be in flight at once: bm_issue does the integer work and starts the two LDS
@@ -229,12 +242,12 @@ __device__ __forceinline__ T lds_load_at(uint32_t byte_addr) {
 __device__ __forceinline__ Bm3Pending bm3_issue(const float *lds_bm, uint32_t ua, uint32_t ub) {
   Bm3Pending p;
   constexpr uint32_t kLow = 23u - kBm3SubBits;                 // mantissa bits below the sub-interval
-  constexpr uint32_t kSide = (32u << kBm3SubBits) * 16u;       // bytes of one side of the radius table
-  const uint32_t mask = static_cast<uint32_t>(static_cast<int32_t>(ua) >> 31);  // all ones when U >= 1/2
-  const uint32_t w1 = __builtin_amdgcn_bitop3_b32(ua, mask, 1u, 0xbe);           // (ua ^ mask) | 1: (0xf0 ^ 0xcc) | 0xaa
-  const uint32_t bits = __float_as_uint(static_cast<float>(w1));                 // exponent 127 .. 158
-  // byte offset of the bin's four coefficients: (exponent low 5 bits : sub-interval) * 16 | side
-  const uint32_t off = ((bits >> (kLow - 4u)) & (kSide - 16u)) | (mask & kSide);
+  static_assert(kLow - 4u == 16u, "the bin's offset is the top half of the float's pattern");
+  // The signed distance of the uniform from the nearer end of (0, 1): ua | 1 read as int32 is w | 1 for
+  // U < 1/2 and -(w | 1) for U >= 1/2 (w = ua ^ (ua >>a 31), the oracle's form: the same values).
+  // v_cvt_f32_i32 rounds the magnitude like v_cvt_f32_u32 and keeps the side as the sign bit.
+  const uint32_t bits = __float_as_uint(static_cast<float>(static_cast<int32_t>(ua | 1u)));  // exponent 127 .. 158
+  const uint32_t off = (bits >> 16) & kBm3RadiusMask;
   p.y = __uint_as_float((bits & ((1u << kLow) - 1u)) | 0x3f800000u);
   (void)lds_bm;
   const f32x4_t kr = lds_load_at<f32x4_t>(off);
@@ -246,7 +259,7 @@ __device__ __forceinline__ Bm3Pending bm3_issue(const float *lds_bm, uint32_t ua
   // mantissa of a float in [1, 1 + 2^-(TRIG_BITS - 9)), then one fma
   const float ya = __uint_as_float((ub & ((1u << kRes) - 1u)) | 0x3f800000u);
   p.delta = __builtin_fmaf(ya, kBm3AngleK, -kBm3AngleC);
-  const f32x2_t cs = lds_load_at<f32x2_t>(aoff + kBm3RadiusEntries * 16u);
+  const f32x2_t cs = lds_load_at<f32x2_t>(aoff + kBm3TrigBytes);
   p.cs = make_float2(cs.x, cs.y);
   return p;
 }
@@ -270,15 +283,21 @@ __device__ __forceinline__ void stage_tables(const KernelArgs &k, float *lds, ui
     float4 *dst = reinterpret_cast<float4 *>(lds);
     for (uint32_t i = threadIdx.x; i < bm_floats(kMode) / 4; i += block) {
       float4 v = src[i];
-      if (kMode == SMMC_MODE_GAUSSIAN && i < kBm3RadiusEntries) {
-        // counter stream v3: each radius coefficient times std, rounded once -- the cubic then yields
-        // r std and the draw needs no multiply of its own
-        v.x *= k.gauss_std;
-        v.y *= k.gauss_std;
-        v.z *= k.gauss_std;
-        v.w *= k.gauss_std;
+      uint32_t at = i;
+      if (kMode == SMMC_MODE_GAUSSIAN) {
+        if (i < kBm3RadiusEntries) {
+          // counter stream v3: each radius coefficient times std, rounded once -- the cubic then yields
+          // r std and the draw needs no multiply of its own; side 1 goes to its own place (kBm3Side1Bytes)
+          v.x *= k.gauss_std;
+          v.y *= k.gauss_std;
+          v.z *= k.gauss_std;
+          v.w *= k.gauss_std;
+          if (i >= kBm3RadiusEntries / 2) at = kBm3Side1Bytes / 16u + (i - kBm3RadiusEntries / 2);
+        } else {
+          at = kBm3TrigBytes / 16u + (i - kBm3RadiusEntries);  // two (cos, sin) pairs per float4
+        }
       }
-      dst[i] = v;
+      dst[at] = v;
     }
   }
 }
@@ -479,7 +498,7 @@ template <int kMode, int kDiv, bool kDense>
 __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float *lds_table = reinterpret_cast<float *>(lds_raw);  // returns table, or the Box-Muller tables
-  const uint32_t table_words = (kMode == SMMC_MODE_TABLE) ? k.table_len : bm_floats(kMode);
+  const uint32_t table_words = (kMode == SMMC_MODE_TABLE) ? k.table_len : bm_lds_words(kMode);
   uint32_t *lds_hist = reinterpret_cast<uint32_t *>(lds_raw) + table_words;
   // The reduction scratch lives BEHIND the tables in the dynamic allocation (paths_lds_bytes), not in
   // static __shared__ arrays: static LDS is placed first, and a draw table that does not start at LDS
@@ -741,7 +760,7 @@ __global__ __launch_bounds__(kKeepdataMaxBlock) void keepdata_kernel(const Kerne
   // number of waves (smmc_engine_simulate_keepdata: 4 in table mode, 12 in Gaussian mode)
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float *lds_table = reinterpret_cast<float *>(lds_raw);
-  const uint32_t table_words = (kMode == SMMC_MODE_TABLE) ? k.table_len : bm_floats(kMode);
+  const uint32_t table_words = (kMode == SMMC_MODE_TABLE) ? k.table_len : bm_lds_words(kMode);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
   const uint32_t stride = ((k.n_periods + 1) & 1u) ? kStrideEven : kStrideOdd;  // uniform
   float *tile = lds_table + table_words + wave * (64 * kRowMax);
@@ -990,7 +1009,7 @@ __global__ __launch_bounds__(kCombMaxBlock) void keepdata_comb_kernel(const Kern
   constexpr int kDraws = Draws<kMode, kDense>::value;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float *lds_table = reinterpret_cast<float *>(lds_raw);
-  const uint32_t table_words = (kMode == SMMC_MODE_TABLE) ? k.table_len : bm_floats(kMode);
+  const uint32_t table_words = (kMode == SMMC_MODE_TABLE) ? k.table_len : bm_lds_words(kMode);
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
   float *tile = lds_table + table_words + wave * comb_tile_words(kDraws);
@@ -1163,7 +1182,7 @@ hipError_t launch_selftest(uint32_t lo, uint32_t hi, unsigned long long *d_count
 // `table_len` is 0 in Gaussian mode, where the Box-Muller tables take the table's place.
 // `table_len` is 0 in Gaussian mode; `stream` (2 | 3) then picks the Box-Muller table set
 static size_t draw_table_words(uint32_t table_len, int stream) {
-  return table_len ? table_len : (stream == 2 ? kBmFloats : kBm3Floats);
+  return table_len ? table_len : (stream == 2 ? kBmFloats : kBm3LdsWords);
 }
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins, int stream) {
   // [draw tables][histogram][pad to 8 bytes][red_scratch: 4 kWaves doubles][wave_part: kWaves BlockPartial]

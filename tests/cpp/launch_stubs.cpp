@@ -22,5 +22,5 @@ uint32_t values_hist_copies(uint32_t) { return 1; }
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins, int) { return (static_cast<size_t>(table_len) + n_bins) * 4u; }
 size_t keepdata_lds_bytes(uint32_t, int, int, int) { return 0; }
 hipError_t static_lds_bytes(size_t *bytes) { *bytes = 0; return hipSuccess; }
-size_t bm_tables_bytes(int stream) { return stream == 2 ? (1056 * 4 + 256 * 2) * 4 : (1024 * 4 + 512 * 2) * 4; }
+size_t bm_tables_bytes(int stream) { return stream == 2 ? (1056 * 4 + 256 * 2) * 4 : (512 * 4 + 2048 * 2) * 4; }
 }  // namespace smmc
