@@ -255,44 +255,46 @@ ORC_API void orc_box_muller(uint32_t ua, uint32_t ub, float *z_cos, float *z_sin
 
 /* ---- counter stream v3: the same construction with cheaper arithmetic ---------------------------
  * (round 2: the Gaussian path step is bound by VALU instruction count; v2 needs 30.5 per period on
- * the device, v3 23.  Table mode is the same in v2 and v3.)
- * Radius: w = ua ^ (ua >>a 31) as before, f = (float)(w | 1) (one three-input bit operation on the
- * device), u = f / 2^32 in (0, 1/2]: exponent 127 .. 158, 32 octaves x 2^SUB_BITS sub-intervals per
- * side, stored rotated so that the table index is ONE bit-field of f, side OR-ed in above it.  The
- * cubic is in y = as_float(0x3f800000 | low mantissa bits), in [1, 1 + 2^-SUB_BITS), as the OR leaves
- * it: the coefficients carry the shift to the bin's middle.  Tail: u >= 2^-32, 6.66 sigma. */
+ * the device, v3 18.  Table mode is the same in v2 and v3.)
+ * Radius: the first word read as int32 is the SIGNED distance d of the uniform from the nearer end of
+ * (0, 1) in units of 2^-32 (d > 0: from 0; d < 0: from 1); f = (float)d (round to nearest even,
+ * |f| <= 2^31), u = |f| / 2^32 in (0, 1/2]; d = 0 stands for u = 2^-33.  Exponent 127 .. 158: 32 octaves x
+ * 2^SUB_BITS sub-intervals per side, stored rotated so that the table index is ONE bit-field of f's
+ * pattern, the side its sign bit.  The cubic is in f itself: the table's coefficients carry the bin's
+ * position, its octave's powers of two and (odd ones) the sign.  Tail: 6.76 sigma at d = 0, 6.66 at 1. */
 #define BM3_LOW_BITS (23 - SMMC_BM3_SUB_BITS)
 #define BM3_SIDE_ENTRIES (32u << SMMC_BM3_SUB_BITS)
 /* r * scale as the kernels form it: every coefficient times scale, rounded once (the device does that
  * while it stages the table in LDS), then the cubic -- the draw needs no multiply of its own.
  * scale = 1 is the radius itself. */
 ORC_API float orc_bm3_radius_scaled(uint32_t ua, float scale) {
-  uint32_t mask = (uint32_t)((int32_t)ua >> 31);
-  uint32_t w1 = (ua ^ mask) | 1u;               /* odd, in [1, 2^31) */
-  uint32_t bits = f2u((float)w1);               /* round to nearest even, exponent 127 .. 158 */
-  uint32_t entry = ((bits >> BM3_LOW_BITS) & (BM3_SIDE_ENTRIES - 1u)) | (mask & BM3_SIDE_ENTRIES);
-  float y = u2f(0x3f800000u | (bits & ((1u << BM3_LOW_BITS) - 1u)));
+  float f = (float)(int32_t)ua;
+  uint32_t bits = f2u(f);                       /* 0, or exponent 127 .. 158 with the side as the sign */
+  uint32_t entry = ((bits >> BM3_LOW_BITS) & (BM3_SIDE_ENTRIES - 1u)) | ((bits >> 31) ? BM3_SIDE_ENTRIES : 0u);
   const float *k = smmc_bm3_radius[entry];
   float k0 = k[0] * scale, k1 = k[1] * scale, k2 = k[2] * scale, k3 = k[3] * scale;
-  return fmaf(fmaf(fmaf(k3, y, k2), y, k1), y, k0);
+  return fmaf(fmaf(fmaf(k3, f, k2), f, k1), f, k0);
 }
 
 ORC_API float orc_bm3_radius(uint32_t ua) { return orc_bm3_radius_scaled(ua, 1.0f); }
 
-/* Angle: theta = 2 pi ub / 2^32 = theta_i + delta, theta_i the MIDDLE of sector i = ub >> (32 -
- * TRIG_BITS) (no rounding add) and delta = (low bits - half a sector) 2 pi / 2^32, |delta| <= dmax =
- * pi / 2^TRIG_BITS, formed WITHOUT an integer-to-float conversion: the low bits are OR-ed into the
- * mantissa of 1.0f and one fma scales and centres them.  The table's (cos, sin) are rotated by delta to
- * FIRST order, (c - s delta, s + c delta): a vector at angle theta_i + atan(delta) (off by delta^3/3
- * <= 1.2e-9) of length sqrt(1 + delta^2); the table carries kappa = 1/sqrt(1 + dmax^2/3), which makes
- * the mean square length 1, so a draw is r cos(theta) times a factor within -3.9e-7 .. +7.8e-7 of 1
- * that depends on where in its sector the angle falls (2048 sectors).  Against a second-order rotation
- * this saves 4 of 25 instructions per pair; the factor is below the binary32 rounding of the draw
- * itself (tests/test_numerics_cpu.py states the bounds). */
+/* Angle: theta = 2 pi (ub mod 2^ANGLE_BITS) / 2^ANGLE_BITS (ANGLE_BITS = 30: the word's top two bits
+ * are not used) = theta_i + delta, theta_i the MIDDLE of sector i = the TRIG_BITS bits below bit 30
+ * (no rounding add; on the device sector * 8 is one masked read of the word's upper half) and delta =
+ * (low 19 bits - half a sector) 2 pi / 2^30, |delta| <= dmax = pi / 2^TRIG_BITS, formed WITHOUT an
+ * integer-to-float conversion: the low bits are OR-ed into the mantissa of 1.0f and one fma scales and
+ * centres them.  The table's (cos, sin) are rotated by delta to FIRST order, (c - s delta, s + c delta):
+ * a vector at angle theta_i + atan(delta) (off by delta^3/3 <= 1.2e-9) of length sqrt(1 + delta^2); the
+ * table carries kappa = 1/sqrt(1 + dmax^2/3), which makes the mean square length 1, so a draw is
+ * r cos(theta) times a factor within -3.9e-7 .. +7.8e-7 of 1 that depends on where in its sector the
+ * angle falls (2048 sectors).  Against a second-order rotation this saves 4 instructions per pair; the
+ * factor is below the binary32 rounding of the draw itself (tests/test_numerics_cpu.py states the
+ * bounds). */
+#define BM3_RES_BITS (SMMC_BM3_ANGLE_BITS - SMMC_BM3_TRIG_BITS)
 ORC_API void orc_box_muller3_scaled(uint32_t ua, uint32_t ub, float scale, float shift, float *d_cos, float *d_sin) {
   float rs = orc_bm3_radius_scaled(ua, scale);
-  uint32_t i = ub >> (32 - SMMC_BM3_TRIG_BITS);
-  float y = u2f(0x3f800000u | (ub & ((1u << (32 - SMMC_BM3_TRIG_BITS)) - 1u)));
+  uint32_t i = (ub >> BM3_RES_BITS) & ((1u << SMMC_BM3_TRIG_BITS) - 1u);
+  float y = u2f(0x3f800000u | (ub & ((1u << BM3_RES_BITS) - 1u)));
   float delta = fmaf(y, SMMC_BM3_ANGLE_K, -SMMC_BM3_ANGLE_C);
   float ci = smmc_bm3_trig[i][0], si = smmc_bm3_trig[i][1];
   float ct = fmaf(-si, delta, ci);
@@ -310,10 +312,9 @@ ORC_API double orc_bm3_radius_scan(uint64_t lo, uint64_t hi, uint64_t stride) {
   double worst = 0.0;
   for (uint64_t a = lo; a < hi; a += stride) {
     uint32_t ua = (uint32_t)a;
-    uint32_t mask = (uint32_t)((int32_t)ua >> 31);
-    uint32_t w1 = (ua ^ mask) | 1u;
-    double u = (double)(float)w1 / 4294967296.0;
-    double want = mask ? sqrt(-2.0 * log1p(-u)) : sqrt(-2.0 * log(u));
+    double f = (double)(float)(int32_t)ua;
+    double u = ua ? fabs(f) / 4294967296.0 : 0x1p-33;
+    double want = f < 0 ? sqrt(-2.0 * log1p(-u)) : sqrt(-2.0 * log(u));
     double e = fabs((double)orc_bm3_radius(ua) - want);
     if (e > worst) worst = e;
   }

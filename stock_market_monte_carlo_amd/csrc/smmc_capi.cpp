@@ -365,6 +365,10 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
   // v2's set first, then v3's
   static_assert(sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig) == (1056 * 4 + 256 * 2) * 4, "v2 table layout");
   static_assert(sizeof(smmc_bm3_radius) + sizeof(smmc_bm3_trig) == (512 * 4 + 2048 * 2) * 4, "v3 table layout");
+  static_assert(smmc::kBm3SubBits == SMMC_BM3_SUB_BITS && smmc::kBm3TrigBits == SMMC_BM3_TRIG_BITS &&
+                    smmc::kBm3AngleBits == SMMC_BM3_ANGLE_BITS && smmc::kBm3AngleK == SMMC_BM3_ANGLE_K &&
+                    smmc::kBm3AngleC == SMMC_BM3_ANGLE_C,
+                "the kernels' v3 constants differ from the generated tables");
   if (smmc::bm_tables_bytes(2) != sizeof(smmc_bm_radius) + sizeof(smmc_bm_trig) ||
       smmc::bm_tables_bytes(3) != sizeof(smmc_bm3_radius) + sizeof(smmc_bm3_trig)) {
     smmc_engine_destroy(e);

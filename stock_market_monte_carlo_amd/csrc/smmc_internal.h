@@ -64,8 +64,8 @@ constexpr uint32_t kHistSpread = 16;
 // Counter stream v3's Box-Muller tables (tools/gen_bm_tables.py; smmc_capi.cpp checks these against the
 // generated smmc_bm_tables.inc): sub-intervals per radius octave, sectors of the angle table, and the two
 // constants of the residual angle delta = fma(y, K, -C).
-constexpr uint32_t kBm3SubBits = 3, kBm3TrigBits = 11;
-constexpr float kBm3AngleK = 0x1.921fb6p-7f, kBm3AngleC = 0x1.c463acp-7f;
+constexpr uint32_t kBm3SubBits = 3, kBm3TrigBits = 11, kBm3AngleBits = 30;
+constexpr float kBm3AngleK = 0x1.921fb6p-5f, kBm3AngleC = 0x1.9eb0b4p-5f;
 
 // radix selection state: per requested rank, the key bits fixed so far and the rank
 // relative to the values that share those bits

@@ -212,20 +212,22 @@ __device__ __forceinline__ void box_muller_scaled(const float *lds_bm, uint32_t 
   bm_finish(bm_issue(lds_bm, ua, ub), scale, shift, d_cos, d_sin);
 }
 
-// Counter stream v3: the same construction with cheaper arithmetic (9.5 instead
-// of 16.5 VALU per draw).  The distance w of the uniform from the nearer end goes to binary32 as w | 1
-// (one v_bitop3 with the XOR that forms w); the radius bin is ONE bit-field of the float -- the
-// octaves are stored rotated -- with the side OR-ed in above it; the cubic's argument is the float the
-// OR of the low mantissa bits into 1.0f leaves (the coefficients carry the shift to the bin's middle);
-// the angle table has 2048 entries at the MIDDLE of their sectors, so the sector is a plain shift of
-// the word, and the residual angle -- low bits OR-ed into 1.0f, one fma, no conversion -- is small
-// enough for a first-order rotation (c - s delta, s + c delta) (the table carries the factor that
-// keeps the mean square length 1); and the draw is the MULTIPLIER itself, fma(r std, cos theta, 100 +
-// mean).
+// Counter stream v3: the same construction with cheaper arithmetic (6 instead
+// of 16.5 VALU per draw).  The first word read as int32 IS the signed distance of the uniform from
+// the nearer end of (0, 1); one v_cvt_f32_i32 turns it into a float f whose pattern holds everything:
+// the radius bin is the top half of the pattern under a mask -- exponent's low five bits and three
+// mantissa bits, the octaves stored rotated, the side left where the float has its sign (one SDWA
+// v_and reading the upper word) -- and the cubic is evaluated in f itself (the coefficients carry the
+// bin's position, the octave's powers of two, the sign and the factor std).  The angle is the low 30
+// bits of the second word: its sector times 8 is again one masked read of the upper word, the table
+// has 2048 entries at the MIDDLE of their sectors, and the residual angle -- low bits OR-ed into 1.0f,
+// one fma, no conversion -- is small enough for a first-order rotation (c - s delta, s + c delta) (the
+// table carries the factor that keeps the mean square length 1); and the draw is the MULTIPLIER
+// itself, fma(r std, cos theta, 100 + mean).
 struct Bm3Pending {
   float4 kr;
   float2 cs;
-  float y, delta;
+  float f, delta;
 };
 
 // A load from an LDS byte address held in a register.  The v3 tables sit at LDS address 0 (the
@@ -241,22 +243,18 @@ __device__ __forceinline__ T lds_load_at(uint32_t byte_addr) {
 
 __device__ __forceinline__ Bm3Pending bm3_issue(const float *lds_bm, uint32_t ua, uint32_t ub) {
   Bm3Pending p;
-  constexpr uint32_t kLow = 23u - kBm3SubBits;                 // mantissa bits below the sub-interval
-  static_assert(kLow - 4u == 16u, "the bin's offset is the top half of the float's pattern");
-  // The signed distance of the uniform from the nearer end of (0, 1): ua | 1 read as int32 is w | 1 for
-  // U < 1/2 and -(w | 1) for U >= 1/2 (w = ua ^ (ua >>a 31), the oracle's form: the same values).
-  // v_cvt_f32_i32 rounds the magnitude like v_cvt_f32_u32 and keeps the side as the sign bit.
-  const uint32_t bits = __float_as_uint(static_cast<float>(static_cast<int32_t>(ua | 1u)));  // exponent 127 .. 158
-  const uint32_t off = (bits >> 16) & kBm3RadiusMask;
-  p.y = __uint_as_float((bits & ((1u << kLow) - 1u)) | 0x3f800000u);
+  static_assert(23u - kBm3SubBits - 4u == 16u, "the bin's offset is the top half of the float's pattern");
+  p.f = static_cast<float>(static_cast<int32_t>(ua));          // |f| <= 2^31; pattern 0 reads bin 0 (u = 2^-33)
+  const uint32_t off = (__float_as_uint(p.f) >> 16) & kBm3RadiusMask;
   (void)lds_bm;
   const f32x4_t kr = lds_load_at<f32x4_t>(off);
   p.kr = make_float4(kr.x, kr.y, kr.z, kr.w);
 
-  constexpr uint32_t kRes = 32u - kBm3TrigBits;                // residual bits below the sector
-  const uint32_t aoff = (ub >> (kRes - 3u)) & ((kBm3TrigEntries - 1u) << 3);  // sector * 8, no rounding add
-  // residual angle from the sector's middle, (low bits - half a sector) 2 pi / 2^32: the low bits as the
-  // mantissa of a float in [1, 1 + 2^-(TRIG_BITS - 9)), then one fma
+  constexpr uint32_t kRes = kBm3AngleBits - kBm3TrigBits;      // residual bits below the sector
+  static_assert(kRes - 3u == 16u, "sector * 8 is the word's upper half under a mask");
+  const uint32_t aoff = (ub >> 16) & ((kBm3TrigEntries - 1u) << 3);  // sector * 8, no rounding add
+  // residual angle from the sector's middle, (low bits - half a sector) 2 pi / 2^30: the low bits as the
+  // mantissa of a float in [1, 1 + 2^-4), then one fma
   const float ya = __uint_as_float((ub & ((1u << kRes) - 1u)) | 0x3f800000u);
   p.delta = __builtin_fmaf(ya, kBm3AngleK, -kBm3AngleC);
   const f32x2_t cs = lds_load_at<f32x2_t>(aoff + kBm3TrigBytes);
@@ -266,7 +264,7 @@ __device__ __forceinline__ Bm3Pending bm3_issue(const float *lds_bm, uint32_t ua
 
 // The staged radius coefficients carry the factor std (stage_tables): the cubic IS r std.
 __device__ __forceinline__ void bm3_finish(const Bm3Pending &p, float shift, float &d_cos, float &d_sin) {
-  const float rs = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(p.kr.w, p.y, p.kr.z), p.y, p.kr.y), p.y, p.kr.x);
+  const float rs = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(p.kr.w, p.f, p.kr.z), p.f, p.kr.y), p.f, p.kr.x);
   const float ct = __builtin_fmaf(-p.cs.y, p.delta, p.cs.x);
   const float st = __builtin_fmaf(p.cs.x, p.delta, p.cs.y);
   d_cos = __builtin_fmaf(rs, ct, shift);

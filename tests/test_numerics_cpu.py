@@ -72,41 +72,58 @@ def test_box_muller_moments_and_accuracy(oracle):
     assert zc == 0.0 and zs == oracle.bm_radius(0)
 
 
+def _v3_u(ua):
+    """The uniform's distance from the nearer end of (0, 1) as counter stream v3 defines it, and its side."""
+    d = np.asarray(ua, dtype=np.int64)
+    d = np.where(d >= 2 ** 31, d - 2 ** 32, d)                       # the word read as int32
+    f = d.astype(np.float32).astype(np.float64)                      # rounded to binary32
+    return np.where(d == 0, 2.0 ** -33, np.abs(f) / 2.0 ** 32), d < 0
+
+
 def test_stream_v3_radius_table_accuracy(oracle):
-    """Counter stream v3's radius: f = fl(w | 1), u = f / 2^32 in (0, 1/2], 32 octaves of 8 sub-intervals
-    stored rotated so that the bin is one bit-field of f, cubic in y = as_float(0x3f800000 | low 20
-    mantissa bits) in [1, 1.125) with the shift to the bin's middle folded into the coefficients.  Same
-    bound as v2's table."""
+    """Counter stream v3's radius: f = fl(d), d the word read as int32 (the signed distance from the
+    nearer end), u = |f| / 2^32 in (0, 1/2] (d = 0: 2^-33), 32 octaves of 8 sub-intervals stored rotated so
+    that the bin is one bit-field of f's pattern and the side its sign, cubic in f itself.  Same bound as
+    v2's table."""
     assert oracle.bm3_radius_scan(0, 2 ** 32, 499) < 6e-7
     assert oracle.bm3_radius_scan(0, 1 << 20, 1) < 6e-7                       # deepest tail, every value
     assert oracle.bm3_radius_scan((1 << 32) - (1 << 20), 1 << 32, 1) < 6e-7  # U -> 1 end (sqrt singularity)
     assert oracle.bm3_radius_scan((1 << 31) - (1 << 18), (1 << 31) + (1 << 18), 1) < 6e-7  # where the sides meet
     # octave boundaries: every power of two of the distance, both neighbours, both sides
-    edges = [v for e in range(1, 31) for v in ((1 << e) - 1, 1 << e, (1 << e) + 1)]
-    for side in (0, 0xFFFFFFFF):
-        got = np.array([oracle.bm3_radius((w ^ side) & 0xFFFFFFFF) for w in edges])
-        u = np.array([float(np.float32(w | 1)) for w in edges]) / 2.0 ** 32
+    edges = np.array([v for e in range(1, 31) for v in ((1 << e) - 1, 1 << e, (1 << e) + 1)], dtype=np.int64)
+    for side in (0, 1):
+        words = edges if side == 0 else (1 << 32) - edges
+        got = np.array([oracle.bm3_radius(int(w)) for w in words])
+        u, neg = _v3_u(words)
+        assert np.all(neg == bool(side))
         want = np.sqrt(-2 * np.log1p(-u)) if side else np.sqrt(-2 * np.log(u))
         assert np.abs(got - want).max() < 6e-7
-    assert oracle.bm3_radius(0) == max(oracle.bm3_radius(a) for a in (0, 1, 2, 1000, 2 ** 31))
-    assert abs(oracle.bm3_radius(0) - np.sqrt(-2 * np.log(2.0 ** -32))) < 1e-6  # 6.66 sigma
+    # the word 0 stands for u = 2^-33 and is the largest radius; then 1 / 2^32, 2 / 2^32, ...
+    assert oracle.bm3_radius(0) == pytest.approx(np.sqrt(-2 * np.log(2.0 ** -33)), abs=1e-6)      # 6.76 sigma
+    assert oracle.bm3_radius(1) == pytest.approx(np.sqrt(-2 * np.log(2.0 ** -32)), abs=1e-6)      # 6.66 sigma
+    assert oracle.bm3_radius(0) > oracle.bm3_radius(1) > oracle.bm3_radius(2) > oracle.bm3_radius(3) > oracle.bm3_radius(1000)
     assert 0 < oracle.bm3_radius(0xFFFFFFFF) < 3e-5
-    assert oracle.bm3_radius(0x7FFFFFFF) == oracle.bm3_radius(0x80000000)   # u = 1/2 from either side
+    # u = 1/2 from either side: the word 2^31 (d = -2^31) and the words that round to +2^31
+    assert oracle.bm3_radius(0x80000000) == oracle.bm3_radius(0x7FFFFFFF) == oracle.bm3_radius(0x7FFFFFC0)
+    assert oracle.bm3_radius(0x80000000) == pytest.approx(np.sqrt(2 * np.log(2.0)), abs=3e-7)
+    # the scaled form multiplies the coefficients, not the result
+    assert oracle.lib().orc_bm3_radius_scaled is not None
 
 
 def test_stream_v3_box_muller_moments_and_accuracy(oracle):
-    """v3 rotates the table's (cos, sin) by the residual angle to FIRST order: the draw is r cos(theta)
-    times sqrt(1 + delta^2) kappa, a factor within -3.9e-7 .. +7.8e-7 of 1 whose mean square is 1, at an
+    """v3's angle is the low 30 bits of the second word, theta = 2 pi (ub mod 2^30) / 2^30, and the
+    table's (cos, sin) are rotated by the residual angle to FIRST order: the draw is r cos(theta) times
+    sqrt(1 + delta^2) kappa, a factor within -3.9e-7 .. +7.8e-7 of 1 whose mean square is 1, at an
     angle off by delta^3/3 <= 1.2e-9.  Checked here: against the exact r cos / sin relative to 1 + r,
     the length factor's range and mean square, and the moments."""
     rng = np.random.default_rng(5)
     ua = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64)
     ub = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64)
     z = np.array([oracle.box_muller3(int(a), int(b)) for a, b in zip(ua, ub)])
-    mask = np.where(ua >> 31, np.uint64(0xFFFFFFFF), np.uint64(0))
-    u = ((ua ^ mask) | np.uint64(1)).astype(np.float32).astype(np.float64) / 2.0 ** 32
-    r = np.where(ua >> 31, np.sqrt(-2 * np.log1p(-u)), np.sqrt(-2 * np.log(u)))
-    th = 2 * np.pi * ub.astype(np.float64) / 2.0 ** 32
+    u, neg = _v3_u(ua)
+    r = np.where(neg, np.sqrt(-2 * np.log1p(-u)), np.sqrt(-2 * np.log(u)))
+    low = (ub % np.uint64(2 ** 30)).astype(np.float64)
+    th = 2 * np.pi * low / 2.0 ** 30
     # |dz|: radius table 5.5e-7 + length factor 7.8e-7 r + binary32 roundings
     assert (np.abs(z[:, 0] - r * np.cos(th)) / (1 + r)).max() < 1.0e-6
     assert (np.abs(z[:, 1] - r * np.sin(th)) / (1 + r)).max() < 1.0e-6
@@ -115,7 +132,7 @@ def test_stream_v3_box_muller_moments_and_accuracy(oracle):
     # radius table and roundings: the same 1.2e-6 as a second-order rotation gave
     n_sec = 2048
     dmax = np.pi / n_sec
-    delta = th - 2 * np.pi * ((ub >> np.uint64(21)).astype(np.float64) + 0.5) / n_sec
+    delta = th - 2 * np.pi * (np.floor(low / 2.0 ** 19) + 0.5) / n_sec
     assert np.abs(delta).max() <= dmax * (1 + 1e-12)
     factor = np.sqrt(1 + delta ** 2) / np.sqrt(1 + dmax ** 2 / 3)
     th1 = th - delta + np.arctan(delta)
@@ -126,12 +143,14 @@ def test_stream_v3_box_muller_moments_and_accuracy(oracle):
     length = np.hypot(z[big, 0], z[big, 1]) / r[big]
     assert abs((length ** 2).mean() - 1) < 5e-8          # no net scale: the variance of the draws is kept
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    # the word's top two bits do not enter the angle
+    assert oracle.box_muller3(12345, 0x12345678) == oracle.box_muller3(12345, 0xD2345678)
     # the scaled form: the kernels draw the MULTIPLIER fma(r std, cos, 100 + mean)
     zc, zs = oracle.box_muller3(123456789, 987654321)
     dc, ds = oracle.box_muller3_scaled(123456789, 987654321, 0.83333, 100.5)
     assert dc == pytest.approx(100.5 + 0.83333 * zc, abs=1e-5) and ds == pytest.approx(100.5 + 0.83333 * zs, abs=1e-5)
     for a, b in [(0, 0), (0xFFFFFFFF, 0xFFFFFFFF), (0, 0x80000000), (0xFFFFFFFF, 0x40000000), (1, 0x3FFFFFFF),
-                 (0x7FFFFFFF, 0x001FFFFF), (0x80000000, 0x00200000), (0x12345678, 0xFFE00000), (5, 0xFFFFFFFF)]:
+                 (0x7FFFFFFF, 0x0007FFFF), (0x80000000, 0x00080000), (0x12345678, 0xFFF80000), (5, 0xFFFFFFFF)]:
         zc, zs = oracle.box_muller3(a, b)
         assert np.isfinite(zc) and np.isfinite(zs) and abs(zc) < 7 and abs(zs) < 7
         assert abs(np.hypot(zc, zs) - oracle.bm3_radius(a)) < 1e-5 * (1 + oracle.bm3_radius(a))
@@ -140,11 +159,11 @@ def test_stream_v3_box_muller_moments_and_accuracy(oracle):
     r0 = oracle.bm3_radius(0)
     zc, zs = oracle.box_muller3(0, 0)
     assert zc == pytest.approx(r0, rel=1e-6) and abs(zs) < 1e-5
-    zc, zs = oracle.box_muller3(0, 0x40000000)
+    zc, zs = oracle.box_muller3(0, 0x10000000)           # a quarter of 2^30
     assert abs(zc) < 1e-5 and zs == pytest.approx(r0, rel=1e-6)
-    zc, zs = oracle.box_muller3(0, 0xFFFFFFFF)  # 2 pi - epsilon: last sector, upper edge
+    zc, zs = oracle.box_muller3(0, 0x3FFFFFFF)           # 2 pi - epsilon: last sector, upper edge
     assert zc == pytest.approx(r0, rel=1e-6) and abs(zs) < 1e-5
-    zc, zs = oracle.box_muller3(0, (37 << 21) | (1 << 20))
+    zc, zs = oracle.box_muller3(0, (37 << 19) | (1 << 18))
     kappa = 1 / np.sqrt(1 + dmax ** 2 / 3)
     assert zc == pytest.approx(r0 * kappa * np.cos(2 * np.pi * 37.5 / n_sec), rel=3e-7)
     assert zs == pytest.approx(r0 * kappa * np.sin(2 * np.pi * 37.5 / n_sec), rel=3e-7)
@@ -159,11 +178,14 @@ def test_stream_v3_return_is_the_multiplier_minus_100(oracle, table):
     for i in range(4):
         rets = oracle.counter_path_returns(p, 12345 + i)
         assert np.array_equal(oracle.many_updates(1000.0, rets, 360).view(np.uint32), r["traj"][i].view(np.uint32))
-    # and the two streams are different transforms of the same uniforms: close, not equal
+    # and the two streams are different transforms of the same uniforms: the same radius (v3 takes the
+    # distance without v2's "| 1" and spells the word 0 as 2^-33), another angle (v3 reads the low 30
+    # bits of the second word, v2 all 32)
     p2 = oracle.make_params(oracle.MODE_GAUSSIAN, 360, 4, 99, first_path=12345, stream=2)
-    r2 = oracle.counter_path_returns(p2, 12345)
-    r3 = oracle.counter_path_returns(p, 12345)
-    assert not np.array_equal(r2, r3) and np.abs(r2 - r3).max() < 2e-5
+    r2 = oracle.counter_path_returns(p2, 12345).astype(np.float64) - 0.5
+    r3 = oracle.counter_path_returns(p, 12345).astype(np.float64) - 0.5
+    assert not np.array_equal(r2, r3)
+    assert np.abs(np.hypot(r2[0::2], r2[1::2]) - np.hypot(r3[0::2], r3[1::2])).max() < 2e-5
     # table mode does not depend on the stream version
     t3 = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 72, 50, 7, table=table))["final"]
     t2 = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 72, 50, 7, table=table, stream=2))["final"]

@@ -45,19 +45,23 @@ def fit_bin(side, c, j):
 
 
 # ---- counter stream v3 -------------------------------------------------------------------------
-# radius: f = fl(w | 1), w the 31-bit distance of the uniform from the nearer end of (0, 1), u = f / 2^32
-# in (0, 1/2].  Exponent 127 .. 158: 32 octaves of 2^SUB3_BITS sub-intervals; table index =
-# (bits >> (23 - SUB3_BITS)) & (32 << SUB3_BITS) - 1 = (exponent << SUB3_BITS | sub) masked, i.e. the
-# octaves are stored rotated (exponent 128 first, exponent 127 last) so that the index is one bit-field
-# extract; side 1 (distance from 1) follows.  The cubic is in y = as_float(0x3f800000 | low mantissa
-# bits), in [1, 1 + 2^-SUB3_BITS), AS IT COMES OUT OF THE OR: the shift to the bin's middle is folded
-# into the coefficients (composition in double, one rounding to binary32).
-# angle: 2^TRIG3_BITS sectors, (cos, sin) at the MIDDLE of each, multiplied by kappa = 1 / sqrt(1 +
-# dmax^2 / 3), dmax = pi / 2^TRIG3_BITS: the kernels rotate by the residual angle delta to FIRST order,
-# (c - s delta, s + c delta), a vector of length sqrt(1 + delta^2); kappa makes its mean square 1.
+# radius: f = fl(d), d = the first word read as int32 = the SIGNED distance of the uniform from the
+# nearer end of (0, 1) in units of 2^-32 (d > 0: from 0, d < 0: from 1; |d| <= 2^31, u = |f| / 2^32 in
+# (0, 1/2]; d = 0 stands for u = 2^-33).  Exponent 127 .. 158: 32 octaves of 2^SUB3_BITS sub-intervals;
+# table index = (bits >> (23 - SUB3_BITS)) & (32 << SUB3_BITS) - 1 = (exponent << SUB3_BITS | sub) masked,
+# i.e. the octaves are stored rotated (exponent 128 first, exponent 127 last) so that the index is one
+# bit-field extract; side 1 (f < 0) follows.  The cubic is IN f ITSELF: r = q0 + f (q1 + f (q2 + f q3)),
+# the bin's position and the powers of two of its octave folded into the coefficients (composed in
+# double, one rounding to binary32; scaling by a power of two is exact), the sign of f into the odd ones.
+# angle: the low ANGLE3_BITS = 30 bits of the second word, theta = 2 pi (ub mod 2^30) / 2^30: the top
+# TRIG3_BITS of them are the sector (sector * 8 is then bits [3, 14) of the word's upper half), (cos, sin)
+# at the MIDDLE of each, multiplied by kappa = 1 / sqrt(1 + dmax^2 / 3), dmax = pi / 2^TRIG3_BITS: the
+# kernels rotate by the residual angle delta to FIRST order, (c - s delta, s + c delta), a vector of
+# length sqrt(1 + delta^2); kappa makes its mean square 1.
 OCT3 = 32
 SUB3_BITS = 3
 TRIG3_BITS = 11
+ANGLE3_BITS = 30
 SUB3 = 1 << SUB3_BITS
 
 
@@ -67,17 +71,25 @@ def fit_bin3(side, c, j):
     coef = Ch.chebfit(nodes * 2.0, radius(u, side), 3)          # T_k(2x), x in [-0.5, 0.5]
     p = Ch.cheb2poly(coef)
     p = np.array([p[k] * 2.0 ** k for k in range(4)])           # power basis in x
-    # x = SUB3 (y - 1) - 0.5: compose
+    if side == 0 and c == 1 and j == 0:
+        # the bin of |f| = 2 is also where f = 0 lands (pattern 0: index 0): the line through
+        # (0, r(2^-33)) and (2, r(2 / 2^32)) serves both
+        r0, r2 = radius(2.0 ** -33, 0), radius(2.0 ** -31, 0)
+        q = np.array([r0, (r2 - r0) / 2.0, 0.0, 0.0])
+        return q.astype(np.float32), 0.0
+    # x = SUB3 (|f| 2^-c - 1) - j - 0.5: compose
     q = np.zeros(4)
-    lin = np.array([-SUB3 - 0.5, float(SUB3)])                  # x as a polynomial in y
+    lin = np.array([-(SUB3 + j + 0.5), SUB3 * 2.0 ** -c])       # x as a polynomial in |f|
     acc = np.array([1.0])
     for k in range(4):
         q[:len(acc)] += p[k] * acc
         acc = Po.polymul(acc, lin)
+    if side == 1:
+        q = q * np.array([1.0, -1.0, 1.0, -1.0])                # f = -|f|
     q32 = q.astype(np.float32)
-    ys = 1.0 + np.linspace(0.0, 1.0, 257) / SUB3
-    us = 2.0 ** (c - 32) * (1.0 + (j + (ys - 1.0) * SUB3) / SUB3)
-    err = np.abs(Po.polyval(ys, q32.astype(np.float64)) - radius(us, side)).max()
+    fs = 2.0 ** c * (1.0 + (j + np.linspace(0.0, 1.0, 257)) / SUB3)
+    sgn = 1.0 if side == 0 else -1.0
+    err = np.abs(Po.polyval(sgn * fs, q32.astype(np.float64)) - radius(fs / 2.0 ** 32, side)).max()
     return q32, err
 
 
@@ -88,8 +100,8 @@ def v3_tables():
             o = t >> SUB3_BITS
             e = 128 + o if o < 31 else 127     # exponent stored at this index
             c, j = e - 127, t & (SUB3 - 1)
-            # octave 31 (exponent 158) holds the single value f = 2^31 (u = 1/2, sub 0, y = 1): its
-            # other sub-intervals are never read and repeat sub-interval 0
+            # octave 31 (exponent 158) holds the single value |f| = 2^31 (u = 1/2, sub 0): its other
+            # sub-intervals are never read and repeat sub-interval 0
             p, err = fit_bin3(side, c, 0 if c == OCT3 - 1 else j)
             worst = max(worst, err)
             rows.append(p)
@@ -131,14 +143,16 @@ def main():
         out.append("  {" + hexf(c) + ", " + hexf(s) + "},")
     out.append("};")
     rows3, trig3, worst3 = v3_tables()
-    k32 = np.float32(2 * np.pi / 512)
-    c32 = np.float32(float(k32) * (1.0 + 2.0 ** (8 - TRIG3_BITS)))
-    out += ["// counter stream v3: radius [side][(exponent << SUB_BITS | sub) masked] x {q0..q3}, r = q0 + y (q1 + y (q2 + y q3)), "
-            f"y in [1, 1 + 2^-SUB_BITS) (see tools/gen_bm_tables.py); max fit error {worst3:.3g}",
+    res_bits = ANGLE3_BITS - TRIG3_BITS                        # residual bits below the sector
+    k32 = np.float32(2 * np.pi * 2.0 ** (23 - ANGLE3_BITS))    # y = 1 + residual / 2^23
+    c32 = np.float32(float(k32) * (1.0 + 2.0 ** (res_bits - 1 - 23)))
+    out += ["// counter stream v3: radius [side][(exponent << SUB_BITS | sub) masked] x {q0..q3}, r = q0 + f (q1 + f (q2 + f q3)), "
+            f"f = (float)(int32) word (see tools/gen_bm_tables.py); max fit error {worst3:.3g}",
             "// trig: (cos, sin) of the sector middles x kappa; residual angle delta = fma(y, ANGLE_K, -ANGLE_C),",
-            "// y = as_float(0x3f800000 | low (32 - TRIG_BITS) bits of the word)",
+            "// y = as_float(0x3f800000 | low (ANGLE_BITS - TRIG_BITS) bits of the word)",
             "#define SMMC_BM3_SUB_BITS %d" % SUB3_BITS,
             "#define SMMC_BM3_TRIG_BITS %d" % TRIG3_BITS,
+            "#define SMMC_BM3_ANGLE_BITS %d" % ANGLE3_BITS,
             "#define SMMC_BM3_ANGLE_K %s" % hexf(k32),
             "#define SMMC_BM3_ANGLE_C %s" % hexf(c32),
             "#define SMMC_BM3_RADIUS_ENTRIES %d" % len(rows3),
