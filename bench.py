@@ -522,7 +522,12 @@ def main():
                          "note": "VALU-bound kernel: 4 B of HBM traffic per path by construction; see valu"},
             "valu": {"bound": "valu-issue", "achieved": valu_ach, "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s",
                      "frac": valu_ach / VALU_PEAK_LANEOPS, "insts_per_path_period": insts,
-                     "note": "unweighted: every VALU instruction counted as one 2-clock issue slot"},
+                     # the roofline's x axis: VALU lane-operations per algorithmic HBM byte of this launch
+                     # (4 bytes written per path), against the ridge point peak ops / peak bytes
+                     "arithmetic_intensity": (periods * insts / 4.0) if (insts and writes_final) else None,
+                     "ridge_point": VALU_PEAK_LANEOPS / (HBM_PEAK_GBS * 1e9),
+                     "note": "unweighted: every VALU instruction counted as one 2-clock issue slot; "
+                             "arithmetic_intensity in lane-ops per HBM byte"},
         }
         if to_host:
             out["host_pipeline"] = {"bytes_to_host_per_step": 4.0 * n, "GBps_rank0": 4.0 * n * args.steps / dt / 1e9,
