@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock = 7.86e13 lane-ops/s
 # VALU instructions per path-period of paths_kernel's inner loop, read off the gfx950 ISA by
 # tools/isa_loop_count.py (tests/test_measurement_cpu.py asserts these equal the built library's).
-VALU_INSTS_PER_STEP = {"gaussian": 72 / 4, "table": 86 / 8}  # Gaussian: counter stream v3 (v2: 122 / 4)
+VALU_INSTS_PER_STEP = {"gaussian": 70 / 4, "table": 84 / 8}  # Gaussian: counter stream v3 (v2: 122 / 4)
 VALU_CHECK_PER_STEP = {"gaussian": 2 / 4, "table": 2 / 8}  # the range-checked divide: two compares per Philox block
 # HBM bytes per launch measured by the round's rocprofv3 PMC passes (tools/pmc_traffic.py writes it)
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -379,7 +379,14 @@ static void digits4(uint32_t h, uint32_t l, uint32_t T, uint32_t idx[4]) {
  * a in [50, 200], where update_fund(total, return) then reproduces total * a / 100 bit for bit). */
 static void path_returns_block(const orc_params *p, uint64_t path, uint32_t blk, float out[8],
                                uint32_t idx_out[8], float mult[8]) {
+  /* counter: stream v3 counts blocks in the FIRST word, (block, path_lo, path_hi, mode) -- on the device
+   * the first two Philox rounds then cost two instructions instead of four --, stream v2 in the third */
   uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), blk, (uint32_t)p->mode};
+  if (p->stream != 2) {
+    ctr[0] = blk;
+    ctr[1] = (uint32_t)path;
+    ctr[2] = (uint32_t)(path >> 32);
+  }
   uint32_t key[2] = {(uint32_t)p->seed, (uint32_t)(p->seed >> 32)};
   uint32_t u[4];
   float a[8];

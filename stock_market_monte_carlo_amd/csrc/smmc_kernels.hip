@@ -34,29 +34,42 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 // Philox4x32-10 (Salmon et al., SC'11).  The key schedule is wave-uniform and
 // lives in SGPRs; per round the lanes pay two 32x32->64 multiplies
 // (v_mad_u64_u32) and two three-input XORs (v_bitop3_b32).
-// kUniformBlock: the caller's c2 (the block index) is wave-uniform.
-template <bool kUniformBlock = false>
+// kUniformFirst: the caller's c0 (counter stream v3: the block index) is wave-uniform and c1, c2 (the
+// path) do not change along the caller's loop.  Rounds 0 and 1 then cost two VALU instructions:
+//   round 0: M0 c0 is a scalar product, M1 c2 per-path constant; n0 = hi(M1 c2) ^ c1 ^ k0 is
+//            per-path constant (hoisted out of the period loop), n2 = hi(M0 c0) ^ c3 ^ k1 scalar;
+//   round 1: M0 n0 per-path constant (hoisted), M1 n2 a scalar product; each XOR has ONE per-lane
+//            term and a scalar pair, which is formed on the SALU (opaque to the compiler, which
+//            otherwise re-associates it apart: an instruction reads at most one SGPR, so a v_bitop3
+//            with two scalar terms costs a v_mov); round 2's first XOR likewise.
+// With the counter (path, block, mode) of stream v2 the same rounds cost four (one multiply among them).
+template <bool kUniformFirst = false>
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = static_cast<uint64_t>(kPhiloxM0) * c0;
     const uint64_t p1 = static_cast<uint64_t>(kPhiloxM1) * c2;
-    // Rounds 0 and 1 as two plain XORs: with the counter (path, block, mode) and a wave-uniform
-    // block index two of the three terms of their first XOR are wave-uniform (round 0: hi(M1 block)
-    // and k0; round 1: lo(M1 block) and k0'); paired in one SALU XOR they leave one two-input VALU XOR
-    // (a v_bitop3 would need a v_mov in front of it: an instruction reads at most one SGPR).  Round
-    // 1's pair the compiler finds; round 0's it re-associates away unless the pair is opaque to it.
-    const uint32_t h1 = static_cast<uint32_t>(p1 >> 32);
-    uint32_t n0;
-    if (r == 0 && kUniformBlock) {
-      uint32_t uniform_pair = h1 ^ k0;
-      asm("" : "+s"(uniform_pair));
-      n0 = uniform_pair ^ c1;
+    const uint32_t h0 = static_cast<uint32_t>(p0 >> 32), h1 = static_cast<uint32_t>(p1 >> 32);
+    uint32_t n0, n2;
+    if (r == 1 && kUniformFirst) {
+      uint32_t pair0 = h1 ^ k0, pair2 = c3 ^ k1;  // scalar ^ scalar
+      asm("" : "+s"(pair0));
+      asm("" : "+s"(pair2));
+      n0 = pair0 ^ c1;
+      n2 = pair2 ^ h0;
+    } else if (r == 2 && kUniformFirst) {  // c1 = lo(M1 n2 of round 0) is still scalar
+      uint32_t pair0 = c1 ^ k0;
+      asm("" : "+s"(pair0));
+      n0 = pair0 ^ h1;
+      n2 = xor3(h0, c3, k1);
+    } else if (r < 2) {  // plain XORs: invariant and scalar parts are the compiler's to hoist and to scalarise
+      n0 = (h1 ^ k0) ^ c1;
+      n2 = (h0 ^ k1) ^ c3;
     } else {
-      n0 = r < 2 ? ((h1 ^ k0) ^ c1) : xor3(h1, c1, k0);
+      n0 = xor3(h1, c1, k0);
+      n2 = xor3(h0, c3, k1);
     }
-    const uint32_t n2 = xor3(static_cast<uint32_t>(p0 >> 32), c3, k1);
     c1 = static_cast<uint32_t>(p1);
     c3 = static_cast<uint32_t>(p0);
     c0 = n0;
@@ -75,7 +88,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // other), so that one wave has 2 N multiplies and 2 N XORs in flight per round instead of 2 + 2.
 // A wave alone can issue a dependent VALU instruction only every 4-8 cycles; below ~6 waves per SIMD
 // this instruction-level parallelism is what fills the issue slots.
-template <int N, bool kUniformBlock = false>
+template <int N, bool kUniformFirst = false>
 __device__ __forceinline__ void philox4x32_10_multi(uint32_t (&c)[N][4], uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
@@ -87,16 +100,26 @@ __device__ __forceinline__ void philox4x32_10_multi(uint32_t (&c)[N][4], uint32_
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const uint32_t h1 = static_cast<uint32_t>(p1[i] >> 32);
-      uint32_t n0;  // rounds 0 and 1: see philox4x32_10
-      if (r == 0 && kUniformBlock) {
-        uint32_t uniform_pair = h1 ^ k0;
-        asm("" : "+s"(uniform_pair));
-        n0 = uniform_pair ^ c[i][1];
+      const uint32_t h0 = static_cast<uint32_t>(p0[i] >> 32), h1 = static_cast<uint32_t>(p1[i] >> 32);
+      uint32_t n0, n2;  // rounds 0 .. 2: see philox4x32_10
+      if (r == 1 && kUniformFirst) {
+        uint32_t pair0 = h1 ^ k0, pair2 = c[i][3] ^ k1;
+        asm("" : "+s"(pair0));
+        asm("" : "+s"(pair2));
+        n0 = pair0 ^ c[i][1];
+        n2 = pair2 ^ h0;
+      } else if (r == 2 && kUniformFirst) {
+        uint32_t pair0 = c[i][1] ^ k0;
+        asm("" : "+s"(pair0));
+        n0 = pair0 ^ h1;
+        n2 = xor3(h0, c[i][3], k1);
+      } else if (r < 2) {
+        n0 = (h1 ^ k0) ^ c[i][1];
+        n2 = (h0 ^ k1) ^ c[i][3];
       } else {
-        n0 = r < 2 ? ((h1 ^ k0) ^ c[i][1]) : xor3(h1, c[i][1], k0);
+        n0 = xor3(h1, c[i][1], k0);
+        n2 = xor3(h0, c[i][3], k1);
       }
-      const uint32_t n2 = xor3(static_cast<uint32_t>(p0[i] >> 32), c[i][3], k1);
       c[i][1] = static_cast<uint32_t>(p1[i]);
       c[i][3] = static_cast<uint32_t>(p0[i]);
       c[i][0] = n0;
@@ -163,8 +186,15 @@ static_assert(kBm3TrigBytes + kBm3TrigEntries * 8u <= kBm3Side1Bytes, "angle tab
 // The kernels' kMode template argument: SMMC_MODE_TABLE (0), SMMC_MODE_GAUSSIAN (1: counter stream
 // v3) or kModeGaussianV2 (the v2 draw, SMMC_FLAG_STREAM_V2).  The Philox counter's mode word is 1
 // for both Gaussian draws: the two streams turn the same uniforms into normals.
-constexpr int kModeGaussianV2 = 2;
-constexpr uint32_t mode_tag(int mode) { return mode == SMMC_MODE_TABLE ? 0u : 1u; }
+constexpr int kModeGaussianV2 = 2, kModeTableV2 = 3;
+constexpr bool is_table(int mode) { return mode == SMMC_MODE_TABLE || mode == kModeTableV2; }
+// Counter stream v3 (SMMC_MODE_TABLE, SMMC_MODE_GAUSSIAN) counts Philox blocks in the counter's FIRST
+// word, (block, path_lo, path_hi, mode); stream v2 (the ...V2 modes) in its third, (path_lo, path_hi,
+// block, mode).  With the block first, a wave-uniform block index and a path that does not change
+// along the period loop the first two Philox rounds cost two VALU instructions instead of four
+// (philox4x32_10).
+constexpr bool counter_v3(int mode) { return mode == SMMC_MODE_TABLE || mode == SMMC_MODE_GAUSSIAN; }
+constexpr uint32_t mode_tag(int mode) { return is_table(mode) ? 0u : 1u; }
 constexpr uint32_t bm_floats(int mode) { return mode == kModeGaussianV2 ? kBmFloats : kBm3Floats; }
 // LDS words the mode's Box-Muller tables take (what follows them starts there)
 constexpr uint32_t bm_lds_words(int mode) { return mode == kModeGaussianV2 ? kBmFloats : kBm3LdsWords; }
@@ -274,7 +304,7 @@ __device__ __forceinline__ void bm3_finish(const Bm3Pending &p, float shift, flo
 // Copies the mode's read-only tables from global memory (L2-resident) into LDS.
 template <int kMode>
 __device__ __forceinline__ void stage_tables(const KernelArgs &k, float *lds, uint32_t block = kBlock) {
-  if constexpr (kMode == SMMC_MODE_TABLE) {
+  if constexpr (is_table(kMode)) {
     for (uint32_t i = threadIdx.x; i < k.table_len; i += block) lds[i] = k.table_a[i];
   } else {
     const float4 *src = reinterpret_cast<const float4 *>(k.bm_tables);
@@ -303,7 +333,7 @@ __device__ __forceinline__ void stage_tables(const KernelArgs &k, float *lds, ui
 // Draws per Philox block: 8 for table mode with T <= 2048 ("dense"), else 4.
 template <int kMode, bool kDense>
 struct Draws {
-  static constexpr int value = (kMode == SMMC_MODE_TABLE && kDense) ? 8 : 4;
+  static constexpr int value = (is_table(kMode) && kDense) ? 8 : 4;
 };
 
 // Four base-T digits of the 64-bit fraction (h:l): digit k = floor(T * frac(T^k x)) by
@@ -327,8 +357,11 @@ __device__ __forceinline__ void block_multipliers(const KernelArgs &k, const flo
                                                   uint32_t path_lo, uint32_t path_hi, uint32_t blk,
                                                   float (&a)[Draws<kMode, kDense>::value]) {
   uint32_t u[4];
-  philox4x32_10<kUniformBlock>(path_lo, path_hi, blk, mode_tag(kMode), k.key0, k.key1, u);
-  if constexpr (kMode == SMMC_MODE_TABLE && kDense) {
+  if constexpr (counter_v3(kMode))
+    philox4x32_10<kUniformBlock>(blk, path_lo, path_hi, mode_tag(kMode), k.key0, k.key1, u);
+  else
+    philox4x32_10<false>(path_lo, path_hi, blk, mode_tag(kMode), k.key0, k.key1, u);
+  if constexpr (is_table(kMode) && kDense) {
     uint32_t ia[4], ib[4];
     digits4(u[0], u[1], k.table_len, ia);
     digits4(u[2], u[3], k.table_len, ib);
@@ -337,7 +370,7 @@ __device__ __forceinline__ void block_multipliers(const KernelArgs &k, const flo
       a[j] = lds_table[ia[j]];
       a[4 + j] = lds_table[ib[j]];
     }
-  } else if constexpr (kMode == SMMC_MODE_TABLE) {
+  } else if constexpr (is_table(kMode)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[j] = lds_table[__umulhi(u[j], k.table_len)];
   } else if constexpr (kMode == kModeGaussianV2) {
@@ -364,13 +397,13 @@ __device__ __forceinline__ void block_multipliers_multi(const KernelArgs &k, con
   uint32_t u[N][4];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    u[i][0] = path_lo;
-    u[i][1] = path_hi;
-    u[i][2] = blk + i;
+    u[i][0] = counter_v3(kMode) ? blk + i : path_lo;
+    u[i][1] = counter_v3(kMode) ? path_lo : path_hi;
+    u[i][2] = counter_v3(kMode) ? path_hi : blk + i;
     u[i][3] = mode_tag(kMode);
   }
-  philox4x32_10_multi<N, kUniformBlock>(u, k.key0, k.key1);
-  if constexpr (kMode == SMMC_MODE_TABLE && kDense) {
+  philox4x32_10_multi<N, kUniformBlock && counter_v3(kMode)>(u, k.key0, k.key1);
+  if constexpr (is_table(kMode) && kDense) {
     uint32_t idx[N][8];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -387,7 +420,7 @@ __device__ __forceinline__ void block_multipliers_multi(const KernelArgs &k, con
     for (int i = 0; i < N; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[i][j] = lds_table[idx[i][j]];
-  } else if constexpr (kMode == SMMC_MODE_TABLE) {
+  } else if constexpr (is_table(kMode)) {
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -496,7 +529,7 @@ template <int kMode, int kDiv, bool kDense>
 __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float *lds_table = reinterpret_cast<float *>(lds_raw);  // returns table, or the Box-Muller tables
-  const uint32_t table_words = (kMode == SMMC_MODE_TABLE) ? k.table_len : bm_lds_words(kMode);
+  const uint32_t table_words = is_table(kMode) ? k.table_len : bm_lds_words(kMode);
   uint32_t *lds_hist = reinterpret_cast<uint32_t *>(lds_raw) + table_words;
   // The reduction scratch lives BEHIND the tables in the dynamic allocation (paths_lds_bytes), not in
   // static __shared__ arrays: static LDS is placed first, and a draw table that does not start at LDS
@@ -758,7 +791,7 @@ __global__ __launch_bounds__(kKeepdataMaxBlock) void keepdata_kernel(const Kerne
   // number of waves (smmc_engine_simulate_keepdata: 4 in table mode, 12 in Gaussian mode)
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float *lds_table = reinterpret_cast<float *>(lds_raw);
-  const uint32_t table_words = (kMode == SMMC_MODE_TABLE) ? k.table_len : bm_lds_words(kMode);
+  const uint32_t table_words = is_table(kMode) ? k.table_len : bm_lds_words(kMode);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
   const uint32_t stride = ((k.n_periods + 1) & 1u) ? kStrideEven : kStrideOdd;  // uniform
   float *tile = lds_table + table_words + wave * (64 * kRowMax);
@@ -1007,7 +1040,7 @@ __global__ __launch_bounds__(kCombMaxBlock) void keepdata_comb_kernel(const Kern
   constexpr int kDraws = Draws<kMode, kDense>::value;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float *lds_table = reinterpret_cast<float *>(lds_raw);
-  const uint32_t table_words = (kMode == SMMC_MODE_TABLE) ? k.table_len : bm_lds_words(kMode);
+  const uint32_t table_words = is_table(kMode) ? k.table_len : bm_lds_words(kMode);
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
   float *tile = lds_table + table_words + wave * comb_tile_words(kDraws);
@@ -1255,6 +1288,9 @@ hipError_t launch_paths(const KernelArgs &a, int div, uint32_t grid, size_t lds_
   if (a.mode != SMMC_MODE_TABLE)
     return a.stream == 2 ? launch_paths_mode<kModeGaussianV2, false>(a, div, grid, lds_bytes, stream)
                          : launch_paths_mode<SMMC_MODE_GAUSSIAN, false>(a, div, grid, lds_bytes, stream);
+  if (a.stream == 2)
+    return table_is_dense(a.table_len) ? launch_paths_mode<kModeTableV2, true>(a, div, grid, lds_bytes, stream)
+                                       : launch_paths_mode<kModeTableV2, false>(a, div, grid, lds_bytes, stream);
   return table_is_dense(a.table_len) ? launch_paths_mode<SMMC_MODE_TABLE, true>(a, div, grid, lds_bytes, stream)
                                      : launch_paths_mode<SMMC_MODE_TABLE, false>(a, div, grid, lds_bytes, stream);
 }
@@ -1339,6 +1375,12 @@ hipError_t launch_keepdata_comb(const KernelArgs &a, bool exact_div, int blocks_
                                                                     n_rows_total, waves, grid, next_chunk, stream)
                          : launch_comb_mode<SMMC_MODE_GAUSSIAN, false>(a, exact_div, blocks_per_step, rows_per_stream, n_wave_chunks,
                                                                        n_rows_total, waves, grid, next_chunk, stream);
+  if (a.stream == 2)
+    return table_is_dense(a.table_len)
+               ? launch_comb_mode<kModeTableV2, true>(a, exact_div, blocks_per_step, rows_per_stream, n_wave_chunks, n_rows_total,
+                                                      waves, grid, next_chunk, stream)
+               : launch_comb_mode<kModeTableV2, false>(a, exact_div, blocks_per_step, rows_per_stream, n_wave_chunks, n_rows_total,
+                                                       waves, grid, next_chunk, stream);
   return table_is_dense(a.table_len)
              ? launch_comb_mode<SMMC_MODE_TABLE, true>(a, exact_div, blocks_per_step, rows_per_stream, n_wave_chunks, n_rows_total,
                                                        waves, grid, next_chunk, stream)
@@ -1356,6 +1398,9 @@ hipError_t launch_keepdata(const KernelArgs &a, bool exact_div, int tile, int wa
   if (a.mode != SMMC_MODE_TABLE)
     return a.stream == 2 ? launch_keepdata_mode<kModeGaussianV2, false>(a, exact_div, tile, waves, grid, stream)
                          : launch_keepdata_mode<SMMC_MODE_GAUSSIAN, false>(a, exact_div, tile, waves, grid, stream);
+  if (a.stream == 2)
+    return table_is_dense(a.table_len) ? launch_keepdata_mode<kModeTableV2, true>(a, exact_div, tile, waves, grid, stream)
+                                       : launch_keepdata_mode<kModeTableV2, false>(a, exact_div, tile, waves, grid, stream);
   return table_is_dense(a.table_len) ? launch_keepdata_mode<SMMC_MODE_TABLE, true>(a, exact_div, tile, waves, grid, stream)
                                      : launch_keepdata_mode<SMMC_MODE_TABLE, false>(a, exact_div, tile, waves, grid, stream);
 }

@@ -31,7 +31,7 @@ def test_valu_instruction_counts_match_the_built_kernels(asm, mode):
     # one LDS gather per period: a table entry, or (Gaussian) a b128 radius row and a b64 trig pair per two periods
     assert I.lds(c) == periods
     # the gfx950 forms the loop is built on are really there
-    assert c["v_bitop3_b32"] >= 17 and c["v_mad_u64_u32"] >= 17
+    assert c["v_bitop3_b32"] >= 15 and c["v_mad_u64_u32"] >= 16
 
 
 def test_pmc_traffic_table_names_its_sources():
