@@ -13,9 +13,9 @@
  * engines may be used concurrently.  No call exits the process: every failure
  * is a negative return code plus smmc_last_error() (thread-local text).
  *
- * Random stream ("counter stream v3"; v2's Gaussian draw stays selectable
+ * Random stream ("counter stream v3"; round 1's stream v2 stays selectable
  * with SMMC_FLAG_STREAM_V2): Philox4x32-10, key =
- * the 64-bit seed, counter = (global path id, block of periods, mode).  A path's value
+ * the 64-bit seed, counter = (block of periods, global path id, mode).  A path's value
  * depends only on (seed, global path id, parameters), never on the launch
  * geometry, the shard it falls in or the number of GPUs.
  */
@@ -43,7 +43,7 @@ extern "C" {
 
 /* smmc_sim.flags */
 #define SMMC_FLAG_EXACT_DIV 1u /* force the IEEE divide kernel variant */
-#define SMMC_FLAG_STREAM_V2 2u /* Gaussian draws of counter stream v2 (round 1) instead of v3; table mode is the same in both */
+#define SMMC_FLAG_STREAM_V2 2u /* counter stream v2 (round 1's) instead of v3: its counter layout (both modes) and its Gaussian draw */
 
 /* paths per chunk of the per-chunk mean/variance outputs: the reference's
  * THREADS_PER_BLOCK (src/simulations.cu:17), one (mean, variance) pair per block
