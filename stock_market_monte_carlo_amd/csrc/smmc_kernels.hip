@@ -533,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
   uint32_t *lds_hist = reinterpret_cast<uint32_t *>(lds_raw) + table_words;
   // The reduction scratch lives BEHIND the tables in the dynamic allocation (paths_lds_bytes), not in
   // static __shared__ arrays: static LDS is placed first, and a draw table that does not start at LDS
-  // address 0 costs one address add per gather (2 of 110 VALU per Philox block in Gaussian mode).
+  // address 0 costs one address add per gather (two VALU instructions per Philox block in Gaussian mode).
   const uint32_t scratch_words = (table_words + ((k.partials != nullptr) ? k.n_bins : 0u) + 1u) & ~1u;  // 8-byte aligned
   double *red_scratch = reinterpret_cast<double *>(reinterpret_cast<uint32_t *>(lds_raw) + scratch_words);  // [4 * kWaves]
   BlockPartial *wave_part = reinterpret_cast<BlockPartial *>(red_scratch + 4 * kWaves);                     // [kWaves]
@@ -1012,7 +1012,8 @@ __global__ __launch_bounds__(kKeepdataMaxBlock) void keepdata_kernel(const Kerne
 // Consequences:
 //   * every piece of control is wave-uniform (SGPRs, scalar branches): the column cursor, the Philox
 //     block index, row ends, tile flushes.  No lane is ever outside its stream, no predicate, no
-//     per-lane delay: 30.5 + ~0.5 VALU per stored value in Gaussian mode (the tile kernel: 39.8).
+//     per-lane delay: the draw and the step + ~2.5 VALU per stored value (20.2 in Gaussian mode; the tile
+//     kernel with stream v2's draw: 39.8, this one: 33.0).
 //   * a stream is stored from its first WHOLE line through the line in which its last row ends, and
 //     it computes the head of the row that follows (the same counter stream: bit-identical to what
 //     that row's own stream computes) to complete that line: every 128-byte line of the output is
