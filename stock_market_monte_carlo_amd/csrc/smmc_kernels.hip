@@ -183,9 +183,10 @@ constexpr uint32_t kBm3Side1Bytes = 0x8000u, kBm3SideBytes = (32u << kBm3SubBits
 constexpr uint32_t kBm3TrigBytes = kBm3SideBytes;                     // LDS byte address of the angle table
 constexpr uint32_t kBm3LdsWords = (kBm3Side1Bytes + kBm3SideBytes) / 4u;
 static_assert(kBm3TrigBytes + kBm3TrigEntries * 8u <= kBm3Side1Bytes, "angle table must fit between the radius sides");
-// The kernels' kMode template argument: SMMC_MODE_TABLE (0), SMMC_MODE_GAUSSIAN (1: counter stream
-// v3) or kModeGaussianV2 (the v2 draw, SMMC_FLAG_STREAM_V2).  The Philox counter's mode word is 1
-// for both Gaussian draws: the two streams turn the same uniforms into normals.
+// The kernels' kMode template argument: SMMC_MODE_TABLE (0) and SMMC_MODE_GAUSSIAN (1) are counter
+// stream v3; kModeGaussianV2 and kModeTableV2 are stream v2 (SMMC_FLAG_STREAM_V2: its counter layout
+// and, in Gaussian mode, its draw).  The Philox counter's mode word is 0 for table draws and 1 for
+// Gaussian draws in both streams.
 constexpr int kModeGaussianV2 = 2, kModeTableV2 = 3;
 constexpr bool is_table(int mode) { return mode == SMMC_MODE_TABLE || mode == kModeTableV2; }
 // Counter stream v3 (SMMC_MODE_TABLE, SMMC_MODE_GAUSSIAN) counts Philox blocks in the counter's FIRST
