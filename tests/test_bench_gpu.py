@@ -46,3 +46,20 @@ def test_rccl_collectives_of_the_multi_rank_path_run_with_one_rank():
     assert d["result"]["hist_total"] == 3000001
     plain = _run("--config", "3", "--total-paths", "3000001", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     assert plain["result"] == d["result"]  # gathered and merged == read directly
+
+
+def test_two_self_launched_ranks_share_the_gpu_and_merge_to_the_single_rank_result():
+    """`python bench.py --gpus 2 --backend gloo`: bench.py starts its own two ranks (both on this box's
+    one GPU), each simulates its half of the global path ids, the records are gathered and merged in
+    rank order: count, below-count and histogram total equal the one-rank run over the same ids, mean
+    and standard deviation to 1e-12."""
+    two = _run("--gpus", "2", "--backend", "gloo", "--config", "3", "--total-paths", "5000001", "--steps", "2",
+               "--warmup", "1", timeout=600)
+    one = _run("--config", "3", "--total-paths", "5000001", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["backend"] == "gloo" and two["launcher"] == "self"
+    assert len(two["devices"]) == 2 and all("cuda:0" in d for d in two["devices"])
+    assert two["config"]["paths_all_ranks"] == 5000001 and two["config"]["paths_rank0"] == 2500001  # the remainder is kept
+    assert two["result"]["hist_total"] == one["result"]["hist_total"] == 5000001
+    assert two["result"]["below_initial"] == one["result"]["below_initial"]
+    assert two["result"]["mean"] == pytest.approx(one["result"]["mean"], rel=1e-12)
+    assert two["result"]["std"] == pytest.approx(one["result"]["std"], rel=1e-10)
