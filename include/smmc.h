@@ -44,6 +44,14 @@ extern "C" {
 /* smmc_sim.flags */
 #define SMMC_FLAG_EXACT_DIV 1u /* force the IEEE divide kernel variant */
 #define SMMC_FLAG_STREAM_V2 2u /* counter stream v2 (round 1's) instead of v3: its counter layout (both modes) and its Gaussian draw */
+/* The reference CPU engine's OWN stream (src/simulations.cpp:240-252), table mode only: path id draws from
+ * std::mt19937 seeded with (uint32_t)(seed + id) -- the reference seeds each path from a fresh
+ * std::random_device and has no seed argument -- through libstdc++'s uniform_int_distribution<int>
+ * (Lemire's map with rejection), then update_fund.  With the seeds the reference's generators got, the
+ * final values are the reference's, bit for bit.  Final-value launches only (smmc_engine_simulate,
+ * smmc_engine_simulate_to_host); statistics and chunk outputs are formed from the final values by a
+ * second pass.  About 3.5x the arithmetic of the default stream (624 words of generator state per path). */
+#define SMMC_FLAG_STREAM_REF 4u
 
 /* paths per chunk of the per-chunk mean/variance outputs: the reference's
  * THREADS_PER_BLOCK (src/simulations.cu:17), one (mean, variance) pair per block

@@ -19,7 +19,8 @@ ABI_VERSION = 2
 MODE_TABLE = 0
 MODE_GAUSSIAN = 1
 FLAG_EXACT_DIV = 1
-FLAG_STREAM_V2 = 2  # Gaussian draws of counter stream v2 instead of v3
+FLAG_STREAM_V2 = 2  # counter stream v2 (round 1's) instead of v3
+FLAG_STREAM_REF = 4  # the reference CPU engine's own stream: per-path mt19937 + libstdc++ Lemire map (table mode)
 CHUNK = 256
 MAX_TABLE = 16384
 MAX_BINS = 4096

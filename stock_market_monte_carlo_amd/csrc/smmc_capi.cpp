@@ -101,6 +101,17 @@ struct smmc_engine {
   unsigned long long *d_work_counter = nullptr;  // the comb keepdata kernel's chunk queue
   unsigned long long *d_hist_spread = nullptr;   // values_stats: kHistSpread copies of the bucket array
 
+  // SMMC_FLAG_STREAM_REF (smmc_ref_kernels.hip)
+  float *d_ref_final = nullptr;     // final values of a launch that asked for none (statistics are formed from them)
+  uint64_t ref_final_cap = 0;
+  uint32_t *d_ref_redo = nullptr;   // [0]: count, [4 ..): paths the windowed kernel left to the generic one
+  uint64_t ref_redo_cap = 0;
+  uint32_t *d_ref_ws = nullptr;     // the generic kernel's generator states
+  uint32_t ref_ws_grid = 0;
+  uint32_t ref_slack = 16;          // SMMC_REF_SLACK: outputs beyond n_periods the windowed kernel may use
+  int ref_kernel = 0;               // SMMC_REF_KERNEL: 0 auto, 1 windowed (where it can), 2 generic
+  uint32_t ref_generic_per_cu = 1;  // SMMC_REF_GENERIC_BLOCKS_PER_CU
+
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;  // pairs: start, stop
   size_t ev_used = 0;
@@ -130,6 +141,11 @@ int check_sim(const smmc_engine *e, const smmc_sim *s) {
     return fail(SMMC_ERR_INVALID, "histogram range must satisfy lo < hi (got %g, %g)", s->hist_lo, s->hist_hi);
   if (s->n_bins && (!std::isfinite(s->hist_lo) || !std::isfinite(s->hist_hi)))
     return fail(SMMC_ERR_INVALID, "histogram range must be finite");
+  if (s->flags & SMMC_FLAG_STREAM_REF) {
+    if (s->mode != SMMC_MODE_TABLE)
+      return fail(SMMC_ERR_INVALID, "SMMC_FLAG_STREAM_REF is the reference's table-draw engine (src/simulations.cpp:240-252): table mode only");
+    if (s->flags & SMMC_FLAG_STREAM_V2) return fail(SMMC_ERR_INVALID, "SMMC_FLAG_STREAM_REF and SMMC_FLAG_STREAM_V2 exclude each other");
+  }
   if (s->n_paths > (1ull << 62)) return fail(SMMC_ERR_INVALID, "n_paths too large");
   if (s->n_periods >= (1u << 31)) return fail(SMMC_ERR_INVALID, "n_periods too large");
   return SMMC_OK;
@@ -231,9 +247,148 @@ int timing_end(smmc_engine *e) {
   return SMMC_OK;
 }
 
+// One pass over n device floats -> packed statistics record (smmc_engine_values_stats after its argument
+// checks; also the statistics of a SMMC_FLAG_STREAM_REF launch).  Device must be current.
+int values_stats_enqueue(smmc_engine *e, const float *d_values, uint64_t n, float below_threshold, uint32_t n_bins,
+                         float hist_lo, float hist_hi, void *d_stats, bool timed) {
+  SMMC_HIP(hipMemsetAsync(d_stats, 0, smmc_stats_bytes(n_bins), e->stream));
+  smmc::ValuesArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.values = d_values;
+  a.n = n;
+  a.below_threshold = below_threshold;
+  a.n_bins = n_bins;
+  a.hist_copies = smmc::values_hist_copies(n_bins);
+  a.hist_lo = hist_lo;
+  a.hist_hi = hist_hi;
+  a.hist_inv = n_bins ? static_cast<double>(n_bins) / (static_cast<double>(hist_hi) - static_cast<double>(hist_lo)) : 0.0;
+  a.partials = e->d_partials;
+  a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
+  if (n_bins && n) {  // spread copies of the bucket array (see ValuesArgs)
+    if (!e->d_hist_spread)
+      SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_hist_spread), sizeof(unsigned long long) * smmc::kHistSpread * SMMC_MAX_BINS));
+    SMMC_HIP(hipMemsetAsync(e->d_hist_spread, 0, sizeof(unsigned long long) * smmc::kHistSpread * n_bins, e->stream));
+    a.hist_spread = e->d_hist_spread;
+    a.spread = smmc::kHistSpread;
+  }
+  // 16 bytes per lane per iteration, 1024-thread workgroups, four per CU: two are resident (32 waves
+  // per CU), the other two queue and even out the CUs' speeds.  1e8 / 1e9 values with the 100-bucket
+  // histogram: 1 per CU 0.102 / 0.758 ms, 2 per CU 0.083 / 0.699, 4 per CU 0.080 / 0.676
+  const uint64_t want = (n / 4 + 1023) / 1024;
+  uint32_t per_cu = 4;
+  if (const char *env = std::getenv("SMMC_STATS_BLOCKS_PER_CU")) {  // tuning knob
+    const long v = std::strtol(env, nullptr, 10);
+    if (v >= 1 && v <= 16) per_cu = static_cast<uint32_t>(v);
+  }
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min(e->compute_units * per_cu, e->max_grid)));
+  if (n) {
+    int rc = timed ? timing_begin(e) : SMMC_OK;
+    if (rc) return rc;
+    SMMC_HIP(smmc::launch_values_stats(a, grid, e->stream));
+    rc = timed ? timing_end(e) : SMMC_OK;
+    if (rc) return rc;
+  }
+  SMMC_HIP(smmc::launch_finalize(e->d_partials, n ? grid : 0u, static_cast<smmc_stats *>(d_stats), n_bins, e->stream,
+                                 a.hist_spread, a.spread));
+  return SMMC_OK;
+}
+
+// SMMC_FLAG_STREAM_REF: the reference's own stream (smmc_ref_kernels.hip).  Launches of at most 2^26 paths:
+// the windowed kernel where a path's outputs fit its window (n_periods + slack <= 454), then a small
+// generic launch over the paths it left (rejections beyond the slack, paths that left the checked
+// divide's window: normally none); the generic kernel for everything when n_periods is larger.
+// Statistics and chunk outputs are second passes over the final values.  Device must be current.
+constexpr uint64_t kRefLaunchPaths = 1ull << 26;
+constexpr uint32_t kRefRedoGrid = 64;
+
+int enqueue_ref_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float *d_chunk_mean, float *d_chunk_var,
+                           void *d_stats) {
+  const uint64_t n = s->n_paths;
+  float *fin = d_final;
+  if (!fin && n) {
+    if (e->ref_final_cap < n) {
+      SMMC_HIP(hipStreamSynchronize(e->stream));
+      if (e->d_ref_final) SMMC_HIP(hipFree(e->d_ref_final));
+      e->d_ref_final = nullptr;
+      e->ref_final_cap = 0;
+      SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_ref_final), sizeof(float) * n));
+      e->ref_final_cap = n;
+    }
+    fin = e->d_ref_final;
+  }
+  const uint32_t T = e->table_len;
+  const uint32_t P = s->n_periods;
+  const bool windowed = e->ref_kernel != 2 && static_cast<uint64_t>(P) + e->ref_slack <= smmc::ref_windowed_max_outputs();
+  const uint32_t full_grid = e->compute_units * e->ref_generic_per_cu;
+  if (n) {
+    const uint64_t seg = std::min<uint64_t>(n, kRefLaunchPaths);
+    if (windowed && e->ref_redo_cap < seg) {
+      SMMC_HIP(hipStreamSynchronize(e->stream));
+      if (e->d_ref_redo) SMMC_HIP(hipFree(e->d_ref_redo));
+      e->d_ref_redo = nullptr;
+      e->ref_redo_cap = 0;
+      SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_ref_redo), sizeof(uint32_t) * (seg + 4)));
+      e->ref_redo_cap = seg;
+    }
+    const uint32_t ws_grid = windowed ? kRefRedoGrid : full_grid;
+    if (e->ref_ws_grid < ws_grid) {
+      SMMC_HIP(hipStreamSynchronize(e->stream));
+      if (e->d_ref_ws) SMMC_HIP(hipFree(e->d_ref_ws));
+      e->d_ref_ws = nullptr;
+      e->ref_ws_grid = 0;
+      SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_ref_ws), smmc::ref_workspace_bytes(ws_grid)));
+      e->ref_ws_grid = ws_grid;
+    }
+    if (static_cast<size_t>(T) * sizeof(float) + 2048 > e->max_lds)
+      return fail(SMMC_ERR_INVALID, "the table needs %zu bytes of LDS, device allows %zu", static_cast<size_t>(T) * 4, e->max_lds);
+    smmc::RefArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.table_a = e->d_table;
+    a.table_len = T;
+    a.reject_below = static_cast<uint32_t>((0x100000000ull - T) % T);  // uniform_int_dist.h:258: -range % range
+    a.n_periods = P;
+    a.initial_capital = s->initial_capital;
+    a.workspace = e->d_ref_ws;
+    int div = divide_kind(e, s, true, &a.chk_lo, &a.chk_hi);
+    int rc = timing_begin(e);
+    if (rc) return rc;
+    for (uint64_t first = 0; first < n; first += seg) {
+      const uint64_t count = std::min<uint64_t>(seg, n - first);
+      a.seed0 = static_cast<uint32_t>(s->seed + s->first_path + first);
+      a.n_paths = static_cast<uint32_t>(count);
+      a.d_final = fin + first;
+      const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((count + smmc::kBlock - 1) / smmc::kBlock, e->max_grid));
+      if (windowed) {
+        a.max_outputs = P + e->ref_slack;
+        a.redo_count = e->d_ref_redo;
+        a.redo_list = e->d_ref_redo + 4;
+        SMMC_HIP(hipMemsetAsync(e->d_ref_redo, 0, sizeof(uint32_t), e->stream));
+        SMMC_HIP(smmc::launch_ref_windowed(a, div, grid, e->stream));
+        SMMC_HIP(smmc::launch_ref_generic(a, true, kRefRedoGrid, e->stream));
+      } else {
+        a.redo_count = nullptr;
+        a.redo_list = nullptr;
+        SMMC_HIP(smmc::launch_ref_generic(a, div != SMMC_DIV_FAST, std::min(grid, full_grid), e->stream));
+      }
+    }
+    rc = timing_end(e);
+    if (rc) return rc;
+  }
+  if (d_chunk_mean || d_chunk_var) {
+    const uint64_t n_chunks = (n + smmc::kBlock - 1) / smmc::kBlock;
+    if (n_chunks)
+      SMMC_HIP(smmc::launch_chunk_stats(fin, n, d_chunk_mean, d_chunk_var,
+                                        static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid)), e->stream));
+  }
+  if (d_stats)
+    return values_stats_enqueue(e, fin, n, s->below_threshold, s->n_bins, s->hist_lo, s->hist_hi, d_stats, false);
+  return SMMC_OK;
+}
+
 // Enqueue: (zero record) -> paths kernel -> finalize.  Device must be current.
 int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float *d_chunk_mean,
                        float *d_chunk_var, void *d_stats) {
+  if (s->flags & SMMC_FLAG_STREAM_REF) return enqueue_ref_simulation(e, s, d_final, d_chunk_mean, d_chunk_var, d_stats);
   smmc::KernelArgs a = make_args(e, s);
   a.d_final = d_final;
   a.d_chunk_mean = d_chunk_mean;
@@ -334,6 +489,17 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     else if (!std::strcmp(env, "chunk")) e->pin_policy = 2;
     else e->pin_policy = 0;
   }
+  if (const char *env = std::getenv("SMMC_REF_SLACK")) {  // test knob, results do not depend on it
+    const long v = std::strtol(env, nullptr, 10);
+    if (v >= 0 && v <= 64) e->ref_slack = static_cast<uint32_t>(v);
+  }
+  if (const char *env = std::getenv("SMMC_REF_KERNEL")) {  // test knob, results do not depend on it
+    e->ref_kernel = !std::strcmp(env, "windowed") ? 1 : !std::strcmp(env, "generic") ? 2 : 0;
+  }
+  if (const char *env = std::getenv("SMMC_REF_GENERIC_BLOCKS_PER_CU")) {  // tuning knob
+    const long v = std::strtol(env, nullptr, 10);
+    if (v >= 1 && v <= 8) e->ref_generic_per_cu = static_cast<uint32_t>(v);
+  }
   // dynamic LDS a launch may ask for: the kernels opt in above the 64 KiB default (CDNA4: 160 KiB per CU)
   e->max_lds = std::max<size_t>(prop.sharedMemPerBlock, 128u * 1024u);
   if (stream != SMMC_STREAM_NEW) {
@@ -417,6 +583,9 @@ void smmc_engine_destroy(smmc_engine *e) {
   if (e->d_scratch_stats) (void)hipFree(e->d_scratch_stats);
   if (e->d_work_counter) (void)hipFree(e->d_work_counter);
   if (e->d_hist_spread) (void)hipFree(e->d_hist_spread);
+  if (e->d_ref_final) (void)hipFree(e->d_ref_final);
+  if (e->d_ref_redo) (void)hipFree(e->d_ref_redo);
+  if (e->d_ref_ws) (void)hipFree(e->d_ref_ws);
   if (e->d_partials) (void)hipFree(e->d_partials);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -475,6 +644,7 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   if ((reinterpret_cast<uintptr_t>(d_traj) | reinterpret_cast<uintptr_t>(d_final)) & 3u)
     return fail(SMMC_ERR_INVALID, "d_traj and d_final must be 4-byte aligned");
   if (sim->n_periods >= (1u << 24)) return fail(SMMC_ERR_INVALID, "keepdata supports n_periods < 2^24");
+  if (sim->flags & SMMC_FLAG_STREAM_REF) return fail(SMMC_ERR_INVALID, "SMMC_FLAG_STREAM_REF: final-value launches only");
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
   if (sim->n_paths == 0) return SMMC_OK;
@@ -822,46 +992,7 @@ int smmc_engine_values_stats(smmc_engine *e, const float *d_values, uint64_t n, 
   if (reinterpret_cast<uintptr_t>(d_stats) & 7u) return fail(SMMC_ERR_INVALID, "d_stats must be 8-byte aligned");
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-  SMMC_HIP(hipMemsetAsync(d_stats, 0, smmc_stats_bytes(n_bins), e->stream));
-  smmc::ValuesArgs a;
-  std::memset(&a, 0, sizeof a);
-  a.values = d_values;
-  a.n = n;
-  a.below_threshold = below_threshold;
-  a.n_bins = n_bins;
-  a.hist_copies = smmc::values_hist_copies(n_bins);
-  a.hist_lo = hist_lo;
-  a.hist_hi = hist_hi;
-  a.hist_inv = n_bins ? static_cast<double>(n_bins) / (static_cast<double>(hist_hi) - static_cast<double>(hist_lo)) : 0.0;
-  a.partials = e->d_partials;
-  a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
-  if (n_bins && n) {  // spread copies of the bucket array (see ValuesArgs)
-    if (!e->d_hist_spread)
-      SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_hist_spread), sizeof(unsigned long long) * smmc::kHistSpread * SMMC_MAX_BINS));
-    SMMC_HIP(hipMemsetAsync(e->d_hist_spread, 0, sizeof(unsigned long long) * smmc::kHistSpread * n_bins, e->stream));
-    a.hist_spread = e->d_hist_spread;
-    a.spread = smmc::kHistSpread;
-  }
-  // 16 bytes per lane per iteration, 1024-thread workgroups, four per CU: two are resident (32 waves
-  // per CU), the other two queue and even out the CUs' speeds.  1e8 / 1e9 values with the 100-bucket
-  // histogram: 1 per CU 0.102 / 0.758 ms, 2 per CU 0.083 / 0.699, 4 per CU 0.080 / 0.676
-  const uint64_t want = (n / 4 + 1023) / 1024;
-  uint32_t per_cu = 4;
-  if (const char *env = std::getenv("SMMC_STATS_BLOCKS_PER_CU")) {  // tuning knob
-    const long v = std::strtol(env, nullptr, 10);
-    if (v >= 1 && v <= 16) per_cu = static_cast<uint32_t>(v);
-  }
-  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min(e->compute_units * per_cu, e->max_grid)));
-  if (n) {
-    int rc = timing_begin(e);
-    if (rc) return rc;
-    SMMC_HIP(smmc::launch_values_stats(a, grid, e->stream));
-    rc = timing_end(e);
-    if (rc) return rc;
-  }
-  SMMC_HIP(smmc::launch_finalize(e->d_partials, n ? grid : 0u, static_cast<smmc_stats *>(d_stats), n_bins, e->stream,
-                                 a.hist_spread, a.spread));
-  return SMMC_OK;
+  return values_stats_enqueue(e, d_values, n, below_threshold, n_bins, hist_lo, hist_hi, d_stats, true);
 }
 
 int smmc_engine_order_statistics(smmc_engine *e, const float *d_values, uint64_t n, const uint64_t *ranks,

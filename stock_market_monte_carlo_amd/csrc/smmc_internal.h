@@ -42,6 +42,30 @@ struct KernelArgs {
   float chk_lo, chk_hi;  // SMMC_DIV_CHECKED only: the window a path must stay in at Philox-block boundaries
 };
 
+// The reference's own stream (SMMC_FLAG_STREAM_REF, smmc_ref_kernels.hip): per-path mt19937 seeded with
+// seed0 + i, libstdc++'s Lemire map onto the table, update_fund -- src/simulations.cpp:240-252.
+struct RefArgs {
+  const float *table_a;   // device, table_len entries, 100.0f + r
+  uint32_t table_len;
+  uint32_t reject_below;  // Lemire: an output whose low product word is below (2^32 - T) % T is rejected
+  uint32_t seed0;         // path i of the launch seeds its generator with (uint32_t)(seed0 + i)
+  uint32_t n_paths;       // <= 2^31 per launch
+  uint32_t n_periods;
+  uint32_t max_outputs;   // windowed kernel: generator outputs a path may use (<= ref_windowed_max_outputs())
+  float initial_capital;
+  float chk_lo, chk_hi;   // SMMC_DIV_CHECKED: as KernelArgs
+  float *d_final;         // n_paths floats
+  uint32_t *redo_count;   // windowed kernel: paths it left unfinished (appended to redo_list); generic kernel
+  uint32_t *redo_list;    //   with redo_list != nullptr: the work items are redo_list[0 .. *redo_count)
+  uint32_t *workspace;    // generic kernel: ref_workspace_bytes(grid)
+};
+uint32_t ref_windowed_max_outputs();
+size_t ref_workspace_bytes(uint32_t grid);
+hipError_t launch_ref_windowed(const RefArgs &a, int div, uint32_t grid, hipStream_t stream);
+hipError_t launch_ref_generic(const RefArgs &a, bool exact_div, uint32_t grid, hipStream_t stream);
+hipError_t launch_chunk_stats(const float *values, uint64_t n, float *d_mean, float *d_var, uint32_t grid,
+                              hipStream_t stream);
+
 // values_stats_kernel arguments (smmc_stats_kernels.hip)
 struct ValuesArgs {
   const float *values;

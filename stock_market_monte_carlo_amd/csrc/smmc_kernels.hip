@@ -14,22 +14,19 @@
 // __builtin_fmaf; results must be bit-identical to oracle/smmc_oracle.c engine (C).
 #include <hip/hip_runtime.h>
 
+#include "smmc_device.h"
 #include "smmc_internal.h"
 
 namespace smmc {
 namespace {
+
+using namespace dev;
 
 constexpr uint32_t kPhiloxM0 = 0xD2511F53u;
 constexpr uint32_t kPhiloxM1 = 0xCD9E8D57u;
 constexpr uint32_t kWeyl0 = 0x9E3779B9u;
 constexpr uint32_t kWeyl1 = 0xBB67AE85u;
 constexpr uint32_t kDenseMaxTable = 2048u;  // largest table drawn eight-per-block
-
-// a ^ b ^ c in one VALU instruction (gfx950 v_bitop3_b32, truth table 0x96); hipcc
-// does not form it from two chained XORs on its own.
-__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
-  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
-}
 
 // Philox4x32-10 (Salmon et al., SC'11).  The key schedule is wave-uniform and
 // lives in SGPRs; per round the lanes pay two 32x32->64 multiplies
@@ -128,32 +125,6 @@ __device__ __forceinline__ void philox4x32_10_multi(uint32_t (&c)[N][4], uint32_
     k0 += kWeyl0;
     k1 += kWeyl1;
   }
-}
-
-// x / 100.0f, correctly rounded, in TWO instructions: 1/100 = ch + cl with ch = fl(1/100) and
-// cl = fl(1/100 - ch); fma(x, ch, fl(x cl)) then equals the IEEE quotient for every binary32 x with
-// |x| >= 2^-114 (Brisebarre and Muller's multiplication by a constant held in two words; whether it is
-// exact for a given constant has to be checked, and for 1/100 it is: exhaustive CPU proof over all
-// 2^23 mantissas of every exponent in tests/test_numerics_cpu.py, device self-test over both signs).
-// Round 1's form -- q = x ch, one FMA for the residual, one for the correction -- took three.  The
-// host only selects it when every product total * a provably stays inside [2^-89, 2^127): there
-// x cl is a normal number as well.
-template <bool kExactDiv>
-__device__ __forceinline__ float div100(float m) {
-  if constexpr (kExactDiv) {
-    return m / 100.0f;  // IEEE divide (hipcc default: correctly rounded)
-  } else {
-    const float ch = 0.01f, cl = 0x1.eb851ep-33f;
-    return __builtin_fmaf(m, ch, m * cl);
-  }
-}
-
-// One compounding period, src/simulations.cpp:14-16 with a = 100.0f + r formed
-// by the caller: total * a, then / 100.
-template <bool kExactDiv>
-__device__ __forceinline__ float compound(float total, float a) {
-  const float m = total * a;
-  return div100<kExactDiv>(m);
 }
 
 // Box-Muller of counter stream v2 through two small LDS tables (generated by
@@ -260,17 +231,6 @@ struct Bm3Pending {
   float2 cs;
   float f, delta;
 };
-
-// A load from an LDS byte address held in a register.  The v3 tables sit at LDS address 0 (the
-// Gaussian kernels have no static __shared__ data -- the host checks that, static_lds_bytes() -- and
-// stage them first in the dynamic allocation), so a bin's byte offset IS its address: going through
-// the `extern __shared__` symbol instead costs a v_add with a link-time constant that turns out to be 0.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-template <typename T>
-__device__ __forceinline__ T lds_load_at(uint32_t byte_addr) {
-  return *reinterpret_cast<const __attribute__((address_space(3))) T *>(static_cast<uintptr_t>(byte_addr));
-}
 
 __device__ __forceinline__ Bm3Pending bm3_issue(const float *lds_bm, uint32_t ua, uint32_t ub) {
   Bm3Pending p;
@@ -456,14 +416,6 @@ __device__ __forceinline__ void block_multipliers_multi(const KernelArgs &k, con
   }
 }
 
-// kDiv: how total * a / 100 is formed.  kDivFast: the reciprocal-multiply form, the host has proven
-// that no product of any path leaves its domain.  kDivExact: the IEEE divide.  kDivChecked: the
-// fast form while the path stays inside a window [chk_lo, chk_hi] tested once per Philox block --
-// wide enough that no product of the FOLLOWING block can leave the domain, whatever it draws --
-// and, for a lane that ever leaves it, the whole path again with the IEEE divide (a real returns
-// table with a +42 % month cannot be proven safe for 360 periods, yet no path ever gets there).
-enum : int { kDivFast = 0, kDivExact = 1, kDivChecked = 2 };
-
 template <int kMode, int kDiv, bool kDense>
 __device__ __forceinline__ float simulate_path(const KernelArgs &k, const float *lds_table,
                                                uint64_t path) {
@@ -499,27 +451,6 @@ __device__ __forceinline__ float simulate_path(const KernelArgs &k, const float 
   }
   return total;
 }
-
-// ---- reductions: wave shuffles, then LDS across the 4 waves ------------------
-
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_down(v, off, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
-  return v;
-}
-
-constexpr int kWaves = kBlock / 64;
 
 // ---- main kernel ---------------------------------------------------------------
 

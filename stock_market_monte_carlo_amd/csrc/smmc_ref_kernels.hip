@@ -1,0 +1,301 @@
+// smmc_ref_kernels.hip -- the reference CPU engine's OWN random stream on gfx950 (SMMC_FLAG_STREAM_REF).
+//
+// The loop of mc_simulations (reference src/simulations.cpp:240-252), one path per lane:
+//     std::mt19937 rng(seed);  std::uniform_int_distribution<int> uni(0, T - 1);
+//     P x { total = update_fund(total, table[uni(rng)]); }
+// with the seed interposed as (uint32_t)(seed0 + path id) where the reference reads a fresh
+// std::random_device per path (it has no seed argument): oracle engine (R), oracle/smmc_oracle.c:143-180.
+// uniform_int_distribution on mt19937 is libstdc++-11's Lemire map with rejection
+// (/usr/include/c++/11/bits/uniform_int_dist.h:241-268), restated here as in the oracle and pinned
+// to the real library by tests/golden/libstdcxx_random.json.
+//
+// mt19937 keeps 624 words of state per generator: 2496 bytes per PATH, 160 KiB per wave -- a CU's whole
+// LDS.  But the state a fresh generator starts from is itself a cheap recurrence,
+//     x[0] = seed,  x[i] = 1812433253 (x[i-1] ^ (x[i-1] >> 30)) + i          (i < 624)
+// and output j is temper(x[624 + j]) with  x[n + 624] = x[n + 397] ^ tw(x[n], x[n + 1]).  So:
+//
+//   ref_windowed_kernel (paths of at most 454 outputs: the reference's 360-period runs): NO state in
+//     memory.  Outputs j < 227 need x[j], x[j+1] and x[j+397], all seed words: two seed chains 397
+//     apart, advanced one step per output (the far one is first run forward 397 steps).  Outputs
+//     227 <= j < 454 need x[624 + (j - 227)], an earlier OUTPUT: it is generated again from two more
+//     seed chains (at j - 227 and j + 170) rather than kept -- three chain steps per output, still
+//     nothing stored, 30-odd VGPRs, full occupancy.
+//   ref_generic_kernel (any length): the classic circular 624-word state, held in a global-memory
+//     workspace laid out [word][lane] so that every access of a wave is one coalesced 256-byte
+//     line; the words a batch of 8 outputs needs are loaded before the batch (none of them is
+//     written inside it), so the loads' latency is paid once per 8 outputs.  One workgroup per CU keeps
+//     the workspace (160 KiB per wave) inside the 256 MiB Infinity Cache.
+//
+// Rejections (T / 2^32 per draw: 2.6e-7 for the 1127-entry table) shift a path's later draws by one
+// output.  Generation stays wave-uniform -- every lane generates output j at step j -- and a lane
+// that rejected simply does not compound at that step; it makes the draw up from the outputs after
+// the P-th (windowed kernel: up to `max_outputs`, else the path goes on the redo list that a small
+// generic launch works off; so does a path that leaves the checked divide's window).
+//
+// Bound: VALU issue, like paths_kernel -- about 29 / 37 instructions per output below / above output
+// 227 plus the 397-step run-up, against 10.5 per period for the Philox table draw.  HBM sees 4 B per path.
+#include <hip/hip_runtime.h>
+
+#include "smmc_device.h"
+#include "smmc_internal.h"
+
+namespace smmc {
+namespace {
+
+using namespace dev;
+
+constexpr uint32_t kMtN = 624, kMtM = 397, kMtLag = kMtN - kMtM;  // 227
+
+// x[i] from x[i-1]: the seeding recurrence of ISO C++ [rand.eng.mers] (oracle mt_seed)
+__device__ __forceinline__ uint32_t mt_seed_step(uint32_t x, uint32_t i) { return 1812433253u * (x ^ (x >> 30)) + i; }
+
+// tw(x[n], x[n+1]) of the twist  x[n + 624] = x[n + 397] ^ tw(x[n], x[n+1])  (oracle mt_twist):
+// y = top bit of x[n] with the low 31 of x[n+1]; (y >> 1) ^ (y odd ? 0x9908b0df : 0)
+__device__ __forceinline__ uint32_t mt_twist_term(uint32_t xn, uint32_t xn1) {
+  const uint32_t y = (xn & 0x80000000u) | (xn1 & 0x7fffffffu);                    // v_bfi_b32
+  const uint32_t odd = static_cast<uint32_t>(static_cast<int32_t>(xn1 << 31) >> 31);  // v_bfe_i32: all ones when odd
+  return __builtin_amdgcn_bitop3_b32(odd, 0x9908b0dfu, y >> 1, 0x6a);             // (odd & magic) ^ (y >> 1)
+}
+
+// tempering (oracle mt_next); a ^ (b & c) is one v_bitop3_b32 (truth table 0x78)
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= y >> 11;
+  y = __builtin_amdgcn_bitop3_b32(y, y << 7, 0x9d2c5680u, 0x78);
+  y = __builtin_amdgcn_bitop3_b32(y, y << 15, 0xefc60000u, 0x78);
+  y ^= y >> 18;
+  return y;
+}
+
+// One generator output `g` (x[624 + j], untempered) offered to a path: the Lemire map picks the table
+// entry or rejects the output; an accepted one is a period (src/simulations.cpp:250).  kMain: the
+// path is known to need the draw (fewer outputs than periods so far).
+template <bool kExactDiv, bool kMain>
+__device__ __forceinline__ void offer(const RefArgs &k, const float *lds_table, uint32_t g, float &total, uint32_t &need) {
+  const uint32_t y = mt_temper(g);
+  const uint64_t prod = static_cast<uint64_t>(y) * k.table_len;
+  const bool accept = static_cast<uint32_t>(prod) >= k.reject_below;
+  const float next = compound<kExactDiv>(total, lds_table[static_cast<uint32_t>(prod >> 32)]);
+  const bool take = kMain ? accept : (accept && need != 0u);
+  total = take ? next : total;
+  need -= take ? 1u : 0u;
+}
+
+// The seed words a path's next output needs, as chains advanced in step with the output index j.
+struct MtWindow {
+  uint32_t seed, x397;  // x[0], x[397]: where the chains of the second stretch start
+  uint32_t a, a1;       // x[j], x[j + 1]
+  uint32_t b;           // j < 227: x[j + 397];  j >= 227: x[j + 170]
+  uint32_t c, c1;       // j >= 227: x[j - 227], x[j - 226]
+};
+
+__device__ __forceinline__ uint32_t window_next_a(MtWindow &w, uint32_t j) {  // outputs 0 .. 226
+  const uint32_t g = w.b ^ mt_twist_term(w.a, w.a1);
+  w.a = w.a1;
+  w.a1 = mt_seed_step(w.a1, j + 2u);
+  w.b = mt_seed_step(w.b, j + kMtM + 1u);
+  return g;
+}
+__device__ __forceinline__ void window_enter_b(MtWindow &w) {
+  w.c = w.seed;
+  w.c1 = mt_seed_step(w.seed, 1u);
+  w.b = w.x397;
+}
+__device__ __forceinline__ uint32_t window_next_b(MtWindow &w, uint32_t j) {  // outputs 227 .. 453
+  // x[j + 397] = x[624 + (j - 227)] = x[j + 170] ^ tw(x[j - 227], x[j - 226]): output j - 227 again
+  const uint32_t g = xor3(w.b, mt_twist_term(w.c, w.c1), mt_twist_term(w.a, w.a1));
+  w.a = w.a1;
+  w.a1 = mt_seed_step(w.a1, j + 2u);
+  w.c = w.c1;
+  w.c1 = mt_seed_step(w.c1, j - kMtLag + 2u);
+  w.b = mt_seed_step(w.b, j + kMtM - kMtLag + 1u);
+  return g;
+}
+
+template <int kDiv>
+__global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
+  extern __shared__ __align__(16) float lds_table[];
+  for (uint32_t i = threadIdx.x; i < k.table_len; i += kBlock) lds_table[i] = k.table_a[i];
+  __syncthreads();
+  constexpr bool kExactDiv = kDiv == kDivExact;
+  const uint32_t P = k.n_periods;
+  const uint32_t n_chunks = (k.n_paths + kBlock - 1u) / kBlock;  // n_paths <= 2^31
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t i = chunk * kBlock + threadIdx.x;
+    const bool active = i < k.n_paths;
+    MtWindow w;
+    w.seed = k.seed0 + i;
+    w.x397 = w.seed;
+    for (uint32_t idx = 1; idx <= kMtM; ++idx) w.x397 = mt_seed_step(w.x397, idx);
+    w.a = w.seed;
+    w.a1 = mt_seed_step(w.seed, 1u);
+    w.b = w.x397;
+    w.c = w.c1 = 0u;
+    float total = k.initial_capital;
+    uint32_t need = P;  // lanes past the end run a path too (nothing of it is stored): `need` stays a plain count
+    bool left = false;
+    auto check = [&]() {  // kDivChecked: the window of divide_kind() (smmc_capi.cpp), at least every 8 periods
+      if constexpr (kDiv == kDivChecked) left |= !(total > k.chk_lo && total < k.chk_hi);
+    };
+    uint32_t j = 0;
+    const uint32_t first = P < kMtLag ? P : kMtLag;
+    for (; j < first; ++j) {
+      offer<kExactDiv, true>(k, lds_table, window_next_a(w, j), total, need);
+      if ((j & 7u) == 7u) check();
+    }
+    if (P > kMtLag) {
+      window_enter_b(w);
+      for (; j < P; ++j) {
+        offer<kExactDiv, true>(k, lds_table, window_next_b(w, j), total, need);
+        if ((j & 7u) == 7u) check();
+      }
+    }
+    // rejected draws are made up from the outputs that follow (rare; wave-uniform trip count)
+    while (j < k.max_outputs && __any(need != 0u)) {
+      uint32_t g;
+      if (j < kMtLag) {
+        g = window_next_a(w, j);
+      } else {
+        if (j == kMtLag) window_enter_b(w);
+        g = window_next_b(w, j);
+      }
+      offer<kExactDiv, false>(k, lds_table, g, total, need);
+      check();
+      ++j;
+    }
+    if (active) {
+      if (need != 0u || left) {
+        k.redo_list[atomicAdd(k.redo_count, 1u)] = i;  // finished by ref_generic_kernel with the IEEE divide
+      } else {
+        k.d_final[i] = total;
+      }
+    }
+  }
+}
+
+// Any number of periods: the circular state in global memory, word s of lane l at workspace[s * L + l]
+// (L = lanes of the launch).  Work items are the paths 0 .. n_paths - 1, or -- redo_list given -- the
+// *redo_count paths the windowed kernel left over.
+template <bool kExactDiv>
+__global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
+  extern __shared__ __align__(16) float lds_table[];
+  for (uint32_t i = threadIdx.x; i < k.table_len; i += kBlock) lds_table[i] = k.table_a[i];
+  __syncthreads();
+  const uint32_t L = gridDim.x * kBlock;
+  uint32_t *const W = k.workspace + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const uint32_t count = k.redo_list ? *k.redo_count : k.n_paths;
+  const uint32_t P = k.n_periods;
+  for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kBlock; base < count; base += L) {
+    const uint64_t item = base + threadIdx.x;
+    const bool active = item < count;
+    const uint32_t i = !active ? 0u : (k.redo_list ? k.redo_list[item] : static_cast<uint32_t>(item));
+    const uint32_t seed = k.seed0 + i;
+    if (P != 0u) {
+      uint32_t x = seed;
+      W[0] = x;
+      for (uint32_t s = 1; s < kMtN; ++s) {
+        x = mt_seed_step(x, s);
+        W[static_cast<size_t>(s) * L] = x;
+      }
+    }
+    float total = k.initial_capital;
+    uint32_t need = active ? P : 0u;
+    uint32_t xn = seed;  // x[j]
+    uint32_t s = 0;      // j mod 624; batches of 8 never straddle the wrap (624 = 8 x 78)
+    auto wrap = [](uint32_t v) { return v >= kMtN ? v - kMtN : v; };
+    while (__any(need != 0u)) {
+      uint32_t n1[8], m[8];
+#pragma unroll
+      for (uint32_t t = 0; t < 8; ++t) {  // x[j + 1 + t], x[j + 397 + t]: none of them written inside this batch
+        n1[t] = W[static_cast<size_t>(wrap(s + 1u + t)) * L];
+        m[t] = W[static_cast<size_t>(wrap(s + kMtM + t)) * L];
+      }
+#pragma unroll
+      for (uint32_t t = 0; t < 8; ++t) {
+        const uint32_t g = m[t] ^ mt_twist_term(xn, n1[t]);
+        W[static_cast<size_t>(s + t) * L] = g;  // x[j + t + 624] takes the place of x[j + t]
+        offer<kExactDiv, false>(k, lds_table, g, total, need);
+        xn = n1[t];
+      }
+      s = wrap(s + 8u);
+    }
+    if (active) k.d_final[i] = total;
+  }
+}
+
+// Mean and population variance of every 256 consecutive values: the per-chunk outputs of paths_kernel
+// (smmc_kernels.hip, same arithmetic in the same order) for launches whose final values come from
+// another kernel.  One workgroup per chunk.
+__global__ __launch_bounds__(kBlock) void chunk_stats_kernel(const float *values, uint64_t n, float *d_mean, float *d_var) {
+  __shared__ double slot[2 * kWaves];
+  const uint64_t n_chunks = (n + kBlock - 1) / kBlock;
+  for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint64_t i = chunk * kBlock + threadIdx.x;
+    const uint64_t left = n - chunk * kBlock;
+    const double n_in = static_cast<double>(left < kBlock ? left : kBlock);
+    const double dv = i < n ? static_cast<double>(values[i]) : 0.0;
+    const double s1 = wave_sum(dv), s2 = wave_sum(dv * dv);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+      slot[wave] = s1;
+      slot[kWaves + wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t1 = slot[0], t2 = slot[kWaves];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) {
+        t1 += slot[w];
+        t2 += slot[kWaves + w];
+      }
+      const double mean = t1 / n_in;
+      const double var = t2 / n_in - mean * mean;
+      if (d_mean) d_mean[chunk] = static_cast<float>(mean);
+      if (d_var) d_var[chunk] = static_cast<float>(var > 0.0 ? var : 0.0);
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+uint32_t ref_windowed_max_outputs() { return kMtN - 170u; }  // 454: outputs the windowed kernel can generate
+size_t ref_workspace_bytes(uint32_t grid) { return static_cast<size_t>(grid) * kBlock * kMtN * sizeof(uint32_t); }
+
+hipError_t launch_ref_windowed(const RefArgs &a, int div, uint32_t grid, hipStream_t stream) {
+  const size_t lds = static_cast<size_t>(a.table_len) * sizeof(float);
+  auto go = [&](auto kernel) {
+    if (lds > 60u * 1024u) {
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+      if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, a);
+    return hipGetLastError();
+  };
+  switch (div) {
+    case SMMC_DIV_FAST: return go(ref_windowed_kernel<kDivFast>);
+    case SMMC_DIV_CHECKED: return go(ref_windowed_kernel<kDivChecked>);
+    default: return go(ref_windowed_kernel<kDivExact>);
+  }
+}
+
+hipError_t launch_ref_generic(const RefArgs &a, bool exact_div, uint32_t grid, hipStream_t stream) {
+  const size_t lds = static_cast<size_t>(a.table_len) * sizeof(float);
+  auto go = [&](auto kernel) {
+    if (lds > 60u * 1024u) {
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+      if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, a);
+    return hipGetLastError();
+  };
+  return exact_div ? go(ref_generic_kernel<true>) : go(ref_generic_kernel<false>);
+}
+
+hipError_t launch_chunk_stats(const float *values, uint64_t n, float *d_mean, float *d_var, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(chunk_stats_kernel, dim3(grid), dim3(kBlock), 0, stream, values, n, d_mean, d_var);
+  return hipGetLastError();
+}
+
+}  // namespace smmc

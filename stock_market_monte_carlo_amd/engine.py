@@ -176,9 +176,11 @@ class Engine:
         s.hist_lo = hist_lo
         s.hist_hi = hist_hi
         s.below_threshold = initial_capital if below_threshold is None else below_threshold
-        if stream not in (2, 3):
-            raise ValueError("stream must be 2 or 3 (the counter stream of the Gaussian draw)")
-        s.flags = (_lib.FLAG_EXACT_DIV if exact_div else 0) | (_lib.FLAG_STREAM_V2 if stream == 2 else 0)
+        if stream not in (2, 3, "ref"):
+            raise ValueError("stream must be 3 or 2 (the counter stream: Philox counter layout in both modes and "
+                             "the Gaussian draw) or 'ref' (the reference CPU engine's per-path mt19937 stream)")
+        s.flags = ((_lib.FLAG_EXACT_DIV if exact_div else 0) | (_lib.FLAG_STREAM_V2 if stream == 2 else 0)
+                   | (_lib.FLAG_STREAM_REF if stream == "ref" else 0))
         return s
 
     def simulate(self, sim, want_final=True, want_chunk_stats=False, want_stats=False, out=None):

@@ -1,5 +1,5 @@
-// launch_stubs.cpp -- CPU sanitizer builds only (make -C oracle asan / tsan): stands in for the two
-// HIP translation units of THIS repository (csrc/smmc_kernels.hip, smmc_stats_kernels.hip), whose device
+// launch_stubs.cpp -- CPU sanitizer builds only (make -C oracle asan / tsan): stands in for the
+// HIP translation units of THIS repository (csrc/smmc_kernels.hip, smmc_ref_kernels.hip, smmc_stats_kernels.hip), whose device
 // code g++ cannot compile, so that the host-side product code (csrc/smmc_capi.cpp, smmc_dropin.cpp) links
 // and its no-GPU paths can run under ASan / UBSan / TSan.  Every launch reports "no device".
 #include "smmc_internal.h"
@@ -22,5 +22,10 @@ uint32_t values_hist_copies(uint32_t) { return 1; }
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins, int) { return (static_cast<size_t>(table_len) + n_bins) * 4u; }
 size_t keepdata_lds_bytes(uint32_t, int, int, int) { return 0; }
 hipError_t static_lds_bytes(size_t *bytes) { *bytes = 0; return hipSuccess; }
+uint32_t ref_windowed_max_outputs() { return 454; }
+size_t ref_workspace_bytes(uint32_t grid) { return static_cast<size_t>(grid) * 256 * 624 * 4; }
+hipError_t launch_ref_windowed(const RefArgs &, int, uint32_t, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_ref_generic(const RefArgs &, bool, uint32_t, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_chunk_stats(const float *, uint64_t, float *, float *, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 size_t bm_tables_bytes(int stream) { return stream == 2 ? (1056 * 4 + 256 * 2) * 4 : (512 * 4 + 2048 * 2) * 4; }
 }  // namespace smmc

@@ -1,0 +1,183 @@
+"""The reference CPU engine's OWN random stream on the device (SMMC_FLAG_STREAM_REF) against
+  (1) tests/golden/libstdcxx_random.json `paths`: whole reference-style paths (src/simulations.cpp:
+      240-252 with explicit seeds) computed by the SYSTEM libstdc++'s std::mt19937 and
+      std::uniform_int_distribution<int> (oracle/pin/pin_libstdcxx.cpp) -- a fixture the C oracle did
+      not produce;
+  (2) oracle engine (R) (orc_ref_mc_simulations: hand-written mt19937 + Lemire map, pinned to the same
+      fixture) at BASELINE configs[0] size (1e6 paths x 360 periods) and across both kernels' edges.
+Final values bit for bit (binary32 patterns); bucket counts, below/underflow/overflow exact; sums 1e-12.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _engine(table, monkeypatch=None, **env):
+    import stock_market_monte_carlo_amd as S
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    e = S.Engine(0)
+    e.set_table(table)
+    return e
+
+
+@pytest.fixture(scope="module")
+def eng(table):
+    e = _engine(table)
+    yield e
+    e.close()
+
+
+def _sim(n, p, seed, first=0, cap=1000.0, **kw):
+    from stock_market_monte_carlo_amd import MODE_TABLE, Engine
+    return Engine.make_sim(n, p, MODE_TABLE, seed, first_path=first, initial_capital=cap, stream="ref", **kw)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_golden_paths_of_the_real_libstdcxx(eng, table):
+    """HIP result == what std::mt19937 + std::uniform_int_distribution<int> + update_fund gave."""
+    pin = json.load(open(os.path.join(HERE, "golden", "libstdcxx_random.json")))
+    assert pin["table_len"] == table.size
+    assert sorted({c["n_periods"] for c in pin["paths"]}) == [1, 4, 360, 1000]
+    for case in pin["paths"]:
+        r = eng.simulate(_sim(32, case["n_periods"], case["seed0"], cap=case["initial_capital"]))
+        eng.sync()
+        got = [int(x) for x in _bits(r.final.cpu().numpy())]
+        assert got == case["final_bits"], (case["n_periods"], case["seed0"])
+        # the seed of path id is (uint32)(seed + id): the same paths as ids 7 .. 38 of seed0 - 7
+        r = eng.simulate(_sim(32, case["n_periods"], case["seed0"] - 7, first=7, cap=case["initial_capital"]))
+        eng.sync()
+        assert [int(x) for x in _bits(r.final.cpu().numpy())] == case["final_bits"]
+
+
+def test_baseline_config0_size_matches_oracle_engine_r(eng, oracle, table):
+    """BASELINE configs[0]: 360 periods x 1e6 paths, every final value, the histogram and the counters."""
+    n, p, seed0 = 1_000_000, 360, 1000
+    want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
+    r = eng.simulate(_sim(n, p, seed0, n_bins=100, hist_lo=0.0, hist_hi=20000.0), want_final=True,
+                     want_chunk_stats=True, want_stats=True)
+    st = eng.read_stats(r.stats_raw)
+    got = r.final.cpu().numpy()
+    assert np.array_equal(_bits(got), _bits(want))
+    ost, ohist = oracle.values_stats(want, 1000.0, 100, 0.0, 20000.0)
+    assert np.array_equal(st.hist, ohist)
+    assert (st.count, st.below, st.underflow, st.overflow) == (n, ost.below, ost.underflow, ost.overflow)
+    assert st.min == ost.min and st.max == ost.max
+    assert st.sum == pytest.approx(ost.sum, rel=1e-12) and st.sumsq == pytest.approx(ost.sumsq, rel=1e-12)
+    om, ov = oracle.chunk_mean_var(want)
+    assert np.allclose(r.chunk_mean.cpu().numpy(), om, rtol=1e-6, atol=0)
+    assert np.allclose(r.chunk_var.cpu().numpy(), ov, rtol=1e-5, atol=1e-3)
+    # statistics only (no caller buffer for the final values): the same record
+    r2 = eng.simulate(_sim(n, p, seed0, n_bins=100, hist_lo=0.0, hist_hi=20000.0), want_final=False, want_stats=True)
+    st2 = eng.read_stats(r2.stats_raw)
+    assert np.array_equal(st2.hist, st.hist) and st2.below == st.below and st2.sum == st.sum
+
+
+# 226/227/228: the windowed kernel's second stretch begins at output 227; 438 is the last length it takes
+# with the default slack of 16 outputs, from 439 on the generic kernel runs; 624/625: the state wraps
+@pytest.mark.parametrize("p", [0, 1, 2, 7, 8, 9, 226, 227, 228, 229, 360, 437, 438, 439, 453, 454, 455, 623, 624, 625, 1000, 1300])
+def test_every_length_both_kernels(eng, oracle, table, p):
+    n, seed0 = 2000 + 77, 4000000000  # ragged; seeds wrap past 2^32 inside the launch window
+    want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
+    r = eng.simulate(_sim(n, p, seed0))
+    eng.sync()
+    assert np.array_equal(_bits(r.final.cpu().numpy()), _bits(want))
+
+
+@pytest.mark.parametrize("kernel", ["windowed", "generic"])
+@pytest.mark.parametrize("exact_div", [False, True])
+def test_forced_kernels_and_divides_agree(table, oracle, monkeypatch, kernel, exact_div):
+    e = _engine(table, monkeypatch, SMMC_REF_KERNEL=kernel)
+    try:
+        for p in (5, 300, 360):
+            n, seed0 = 30011, 99
+            want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
+            r = e.simulate(_sim(n, p, seed0, exact_div=exact_div))
+            e.sync()
+            assert np.array_equal(_bits(r.final.cpu().numpy()), _bits(want)), (kernel, exact_div, p)
+    finally:
+        e.close()
+
+
+def test_rejections_take_the_redo_path(table, oracle, monkeypatch):
+    """With no slack a path that rejects one generator output cannot finish in the windowed kernel: it goes
+    on the redo list and the generic kernel finishes it.  T = 12289 rejects 2.1e-6 of the outputs: a few
+    hundred of the 4e5 paths."""
+    rng = np.random.default_rng(5)
+    big = rng.normal(0.6, 4.3, 12289).astype(np.float32)
+    threshold = (2 ** 32 - big.size) % big.size
+    n, p, seed0 = 400_000, 360, 31337
+    # how many paths reject at least once (from the oracle's index stream, independent of the engine)
+    want, _ = oracle.ref_mc_simulations(n, p, 1000.0, big, seed0)
+    expect_rejecting = n * (1.0 - (1.0 - threshold / 2.0 ** 32) ** p)
+    assert 50 < expect_rejecting < 5000
+    for slack in (0, 1, 16):
+        e = _engine(big, monkeypatch, SMMC_REF_SLACK=slack)
+        try:
+            r = e.simulate(_sim(n, p, seed0))
+            e.sync()
+            assert np.array_equal(_bits(r.final.cpu().numpy()), _bits(want)), slack
+        finally:
+            e.close()
+
+
+def test_checked_divide_window_and_overflowing_paths(table, oracle, monkeypatch):
+    """A table with +60 % entries cannot be proven safe for the fast divide over 400 periods (CHECKED);
+    with a capital of 1e30 most paths really leave the window and about half overflow to inf: those come
+    back from the generic kernel with the IEEE divide, bit for bit the oracle's."""
+    from stock_market_monte_carlo_amd._lib import DIV_CHECKED
+    t = table.copy()
+    t[::10] = 60.0
+    e = _engine(t, monkeypatch)
+    try:
+        for cap in (1000.0, 1e30):
+            sim = _sim(20011, 400, 7, cap=cap)
+            assert e.divide_kind(sim) == DIV_CHECKED
+            want, _ = oracle.ref_mc_simulations(20011, 400, cap, t, 7)
+            r = e.simulate(sim)
+            e.sync()
+            got = r.final.cpu().numpy()
+            assert np.array_equal(_bits(got), _bits(want)), cap
+        assert np.isinf(want).any() and np.isfinite(want).any()
+    finally:
+        e.close()
+
+
+def test_host_pipeline_chunks_and_shards(eng, oracle, table, monkeypatch):
+    """simulate_to_host in several chunks, and two shards of one run == the whole run (first_path offsets)."""
+    n, p, seed0 = 300_000, 360, 123456789
+    want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
+    e = _engine(table, monkeypatch, SMMC_HOST_CHUNK_PATHS=65536)
+    try:
+        host, st, _ = e.simulate_to_host(_sim(n, p, seed0, n_bins=50, hist_lo=0.0, hist_hi=30000.0), want_stats=True)
+        assert np.array_equal(_bits(host), _bits(want))
+        ost, ohist = oracle.values_stats(want, 1000.0, 50, 0.0, 30000.0)
+        assert np.array_equal(st.hist, ohist) and st.below == ost.below and st.count == n
+    finally:
+        e.close()
+    a = eng.simulate(_sim(100_001, p, seed0))
+    b = eng.simulate(_sim(n - 100_001, p, seed0, first=100_001))
+    eng.sync()
+    assert np.array_equal(_bits(np.concatenate([a.final.cpu().numpy(), b.final.cpu().numpy()])), _bits(want))
+
+
+def test_argument_errors(eng):
+    from stock_market_monte_carlo_amd import MODE_GAUSSIAN, Engine, SmmcError
+    sim = Engine.make_sim(10, 4, MODE_GAUSSIAN, 1, stream="ref")
+    with pytest.raises(SmmcError, match="table mode only"):
+        eng.simulate(sim)
+    with pytest.raises(SmmcError, match="final-value launches only"):
+        eng.simulate_keepdata(_sim(10, 4, 1))
+    # empty launch: a zero record, nothing written
+    r = eng.simulate(_sim(0, 360, 1, n_bins=10, hist_lo=0.0, hist_hi=1.0), want_final=True, want_stats=True)
+    st = eng.read_stats(r.stats_raw)
+    assert st.count == 0 and int(st.hist.sum()) == 0

@@ -1,0 +1,45 @@
+"""Times the reference-stream kernels (SMMC_FLAG_STREAM_REF, smmc_ref_kernels.hip) with HIP events on the
+engine's stream: the windowed kernel at 360 periods, the generic kernel at 1000, beside the default
+Philox table stream on the same shapes.  One JSON line per case.
+
+usage: bench_ref.py [n_paths_360] [n_paths_1000]
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import stock_market_monte_carlo_amd as S  # noqa: E402
+from tests.conftest import load_table  # noqa: E402
+
+
+def main():
+    import torch
+    n360 = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
+    n1000 = int(float(sys.argv[2])) if len(sys.argv) > 2 else 20_000_000
+    table = load_table()
+    eng = S.Engine(0)
+    eng.set_table(table)
+    for name, n, p, stream in (("ref windowed", n360, 360, "ref"), ("philox table", n360, 360, 3),
+                               ("ref generic", n1000, 1000, "ref"), ("philox table", n1000, 1000, 3)):
+        sim = S.Engine.make_sim(n, p, S.MODE_TABLE, 1000, stream=stream)
+        out = torch.empty(n, dtype=torch.float32, device=eng.tdevice)
+        eng.simulate(sim, out=out)
+        eng.sync()
+        eng.timing(True)
+        reps = 5
+        for _ in range(reps):
+            eng.simulate(sim, out=out)
+        ms, k = eng.kernel_ms()
+        eng.timing(False)
+        ms /= max(k, 1)
+        print(json.dumps({"case": name, "n_paths": n, "n_periods": p, "kernel_ms": ms, "paths_per_s": n / ms * 1e3,
+                          "hbm_GBps_final_values": 4.0 * n / ms / 1e6, "divide": ("fast", "exact", "checked")[eng.divide_kind(sim)],
+                          "mean": float(out.double().mean())}), flush=True)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
