@@ -108,7 +108,6 @@ struct smmc_engine {
   uint64_t ref_redo_cap = 0;
   uint32_t *d_ref_ws = nullptr;     // the generic kernel's generator states
   uint32_t ref_ws_grid = 0;
-  uint32_t ref_slack = 16;          // SMMC_REF_SLACK: outputs beyond n_periods the windowed kernel may use
   int ref_kernel = 0;               // SMMC_REF_KERNEL: 0 auto, 1 windowed (where it can), 2 generic
   uint32_t ref_generic_per_cu = 1;  // SMMC_REF_GENERIC_BLOCKS_PER_CU
 
@@ -294,9 +293,10 @@ int values_stats_enqueue(smmc_engine *e, const float *d_values, uint64_t n, floa
 }
 
 // SMMC_FLAG_STREAM_REF: the reference's own stream (smmc_ref_kernels.hip).  Launches of at most 2^26 paths:
-// the windowed kernel where a path's outputs fit its window (n_periods + slack <= 454), then a small
-// generic launch over the paths it left (rejections beyond the slack, paths that left the checked
-// divide's window: normally none); the generic kernel for everything when n_periods is larger.
+// the windowed kernel where a path's outputs fit its window (n_periods <= 454), then a small generic
+// launch over the paths it left (a rejected generator output -- 1e-4 of the paths with the 1127-entry
+// table at 360 periods -- or a path that left the checked divide's window); the generic kernel for
+// everything when n_periods is larger.
 // Statistics and chunk outputs are second passes over the final values.  Device must be current.
 constexpr uint64_t kRefLaunchPaths = 1ull << 26;
 constexpr uint32_t kRefRedoGrid = 64;
@@ -318,7 +318,7 @@ int enqueue_ref_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, fl
   }
   const uint32_t T = e->table_len;
   const uint32_t P = s->n_periods;
-  const bool windowed = e->ref_kernel != 2 && static_cast<uint64_t>(P) + e->ref_slack <= smmc::ref_windowed_max_outputs();
+  const bool windowed = e->ref_kernel != 2 && P <= smmc::ref_windowed_max_outputs();
   const uint32_t full_grid = e->compute_units * e->ref_generic_per_cu;
   if (n) {
     const uint64_t seg = std::min<uint64_t>(n, kRefLaunchPaths);
@@ -359,7 +359,6 @@ int enqueue_ref_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, fl
       a.d_final = fin + first;
       const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((count + smmc::kBlock - 1) / smmc::kBlock, e->max_grid));
       if (windowed) {
-        a.max_outputs = P + e->ref_slack;
         a.redo_count = e->d_ref_redo;
         a.redo_list = e->d_ref_redo + 4;
         SMMC_HIP(hipMemsetAsync(e->d_ref_redo, 0, sizeof(uint32_t), e->stream));
@@ -488,10 +487,6 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     if (!std::strcmp(env, "1") || !std::strcmp(env, "whole")) e->pin_policy = 1;
     else if (!std::strcmp(env, "chunk")) e->pin_policy = 2;
     else e->pin_policy = 0;
-  }
-  if (const char *env = std::getenv("SMMC_REF_SLACK")) {  // test knob, results do not depend on it
-    const long v = std::strtol(env, nullptr, 10);
-    if (v >= 0 && v <= 64) e->ref_slack = static_cast<uint32_t>(v);
   }
   if (const char *env = std::getenv("SMMC_REF_KERNEL")) {  // test knob, results do not depend on it
     e->ref_kernel = !std::strcmp(env, "windowed") ? 1 : !std::strcmp(env, "generic") ? 2 : 0;

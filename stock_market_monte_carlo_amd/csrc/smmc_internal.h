@@ -50,8 +50,7 @@ struct RefArgs {
   uint32_t reject_below;  // Lemire: an output whose low product word is below (2^32 - T) % T is rejected
   uint32_t seed0;         // path i of the launch seeds its generator with (uint32_t)(seed0 + i)
   uint32_t n_paths;       // <= 2^31 per launch
-  uint32_t n_periods;
-  uint32_t max_outputs;   // windowed kernel: generator outputs a path may use (<= ref_windowed_max_outputs())
+  uint32_t n_periods;     // windowed kernel: <= ref_windowed_max_outputs()
   float initial_capital;
   float chk_lo, chk_hi;   // SMMC_DIV_CHECKED: as KernelArgs
   float *d_final;         // n_paths floats

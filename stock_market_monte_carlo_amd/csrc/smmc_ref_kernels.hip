@@ -27,13 +27,12 @@
 //     the workspace (160 KiB per wave) inside the 256 MiB Infinity Cache.
 //
 // Rejections (T / 2^32 per draw: 2.6e-7 for the 1127-entry table) shift a path's later draws by one
-// output.  Generation stays wave-uniform -- every lane generates output j at step j -- and a lane
-// that rejected simply does not compound at that step; it makes the draw up from the outputs after
-// the P-th (windowed kernel: up to `max_outputs`, else the path goes on the redo list that a small
-// generic launch works off; so does a path that leaves the checked divide's window).
+// output.  Generation stays wave-uniform -- every lane generates output j at step j.  In the generic
+// kernel a lane that rejected simply does not compound at that step and goes on past output P; the
+// windowed kernel only flags it: the path goes on the redo list that a small generic launch works
+// off (so does a path that leaves the checked divide's window).
 //
-// Bound: VALU issue, like paths_kernel -- about 29 / 37 instructions per output below / above output
-// 227 plus the 397-step run-up, against 10.5 per period for the Philox table draw.  HBM sees 4 B per path.
+// Bound: VALU issue, like paths_kernel (DESIGN.md section 5 has the counts).  HBM sees 4 B per path.
 #include <hip/hip_runtime.h>
 
 #include "smmc_device.h"
@@ -50,11 +49,15 @@ constexpr uint32_t kMtN = 624, kMtM = 397, kMtLag = kMtN - kMtM;  // 227
 __device__ __forceinline__ uint32_t mt_seed_step(uint32_t x, uint32_t i) { return 1812433253u * (x ^ (x >> 30)) + i; }
 
 // tw(x[n], x[n+1]) of the twist  x[n + 624] = x[n + 397] ^ tw(x[n], x[n+1])  (oracle mt_twist):
-// y = top bit of x[n] with the low 31 of x[n+1]; (y >> 1) ^ (y odd ? 0x9908b0df : 0)
-__device__ __forceinline__ uint32_t mt_twist_term(uint32_t xn, uint32_t xn1) {
-  const uint32_t y = (xn & 0x80000000u) | (xn1 & 0x7fffffffu);                    // v_bfi_b32
+// y = top bit of x[n] with the low 31 of x[n+1]; (y >> 1) ^ (y odd ? 0x9908b0df : 0).  The callers keep
+// the halves h = x >> 1 of the words they walk over (each word is x[n+1] once and x[n] the step after):
+// y >> 1 is then h[n+1] with its bit 30 taken from h[n] -- one v_bfi_b32, whose mask 0x40000000 is the
+// inline constant 2.0.
+__device__ __forceinline__ uint32_t mt_twist_term(uint32_t hn, uint32_t hn1, uint32_t xn1) {
+  uint32_t ysh;  // (hn & 0x40000000) | (hn1 & ~0x40000000); left to itself hipcc takes three instructions
+  asm("v_bfi_b32 %0, 2.0, %1, %2" : "=v"(ysh) : "v"(hn), "v"(hn1));
   const uint32_t odd = static_cast<uint32_t>(static_cast<int32_t>(xn1 << 31) >> 31);  // v_bfe_i32: all ones when odd
-  return __builtin_amdgcn_bitop3_b32(odd, 0x9908b0dfu, y >> 1, 0x6a);             // (odd & magic) ^ (y >> 1)
+  return __builtin_amdgcn_bitop3_b32(odd, 0x9908b0dfu, ysh, 0x6a);                   // (odd & magic) ^ (y >> 1)
 }
 
 // tempering (oracle mt_next); a ^ (b & c) is one v_bitop3_b32 (truth table 0x78)
@@ -66,16 +69,15 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   return y;
 }
 
-// One generator output `g` (x[624 + j], untempered) offered to a path: the Lemire map picks the table
-// entry or rejects the output; an accepted one is a period (src/simulations.cpp:250).  kMain: the
-// path is known to need the draw (fewer outputs than periods so far).
-template <bool kExactDiv, bool kMain>
+// One generator output `g` (x[624 + j], untempered) offered to a path that still needs `need` draws: the
+// Lemire map picks the table entry or rejects the output; an accepted one is a period
+// (src/simulations.cpp:250).
+template <bool kExactDiv>
 __device__ __forceinline__ void offer(const RefArgs &k, const float *lds_table, uint32_t g, float &total, uint32_t &need) {
   const uint32_t y = mt_temper(g);
   const uint64_t prod = static_cast<uint64_t>(y) * k.table_len;
-  const bool accept = static_cast<uint32_t>(prod) >= k.reject_below;
+  const bool take = static_cast<uint32_t>(prod) >= k.reject_below && need != 0u;
   const float next = compound<kExactDiv>(total, lds_table[static_cast<uint32_t>(prod >> 32)]);
-  const bool take = kMain ? accept : (accept && need != 0u);
   total = take ? next : total;
   need -= take ? 1u : 0u;
 }
@@ -83,87 +85,103 @@ __device__ __forceinline__ void offer(const RefArgs &k, const float *lds_table, 
 // The seed words a path's next output needs, as chains advanced in step with the output index j.
 struct MtWindow {
   uint32_t seed, x397;  // x[0], x[397]: where the chains of the second stretch start
-  uint32_t a, a1;       // x[j], x[j + 1]
+  uint32_t ah, a1, a1h; // x[j] >> 1, x[j + 1], x[j + 1] >> 1
   uint32_t b;           // j < 227: x[j + 397];  j >= 227: x[j + 170]
-  uint32_t c, c1;       // j >= 227: x[j - 227], x[j - 226]
+  uint32_t ch, c1, c1h; // j >= 227: x[j - 227] >> 1, x[j - 226], x[j - 226] >> 1
 };
 
-__device__ __forceinline__ uint32_t window_next_a(MtWindow &w, uint32_t j) {  // outputs 0 .. 226
-  const uint32_t g = w.b ^ mt_twist_term(w.a, w.a1);
-  w.a = w.a1;
+__device__ __forceinline__ void window_enter_a(MtWindow &w) {
+  w.ah = w.seed >> 1;
+  w.a1 = mt_seed_step(w.seed, 1u);
+  w.a1h = w.a1 >> 1;
+  w.b = w.x397;
+}
+// `far` = j + 398, the index of the far chain's next word, is the caller's own scalar counter: formed
+// as j + 398 it is a second v_add per step (398 is no inline constant), as far + t it is part of a v_add3.
+__device__ __forceinline__ uint32_t window_next_a(MtWindow &w, uint32_t j, uint32_t far) {  // outputs 0 .. 226
+  const uint32_t g = w.b ^ mt_twist_term(w.ah, w.a1h, w.a1);
+  w.ah = w.a1h;
   w.a1 = mt_seed_step(w.a1, j + 2u);
-  w.b = mt_seed_step(w.b, j + kMtM + 1u);
+  w.a1h = w.a1 >> 1;
+  w.b = mt_seed_step(w.b, far);
   return g;
 }
 __device__ __forceinline__ void window_enter_b(MtWindow &w) {
-  w.c = w.seed;
+  w.ch = w.seed >> 1;
   w.c1 = mt_seed_step(w.seed, 1u);
+  w.c1h = w.c1 >> 1;
   w.b = w.x397;
 }
-__device__ __forceinline__ uint32_t window_next_b(MtWindow &w, uint32_t j) {  // outputs 227 .. 453
+// `near` = j - 225 and `far` = j + 171: the next words of the two replayed chains (own counters, as above)
+__device__ __forceinline__ uint32_t window_next_b(MtWindow &w, uint32_t j, uint32_t near, uint32_t far) {  // outputs 227 .. 453
   // x[j + 397] = x[624 + (j - 227)] = x[j + 170] ^ tw(x[j - 227], x[j - 226]): output j - 227 again
-  const uint32_t g = xor3(w.b, mt_twist_term(w.c, w.c1), mt_twist_term(w.a, w.a1));
-  w.a = w.a1;
+  const uint32_t g = xor3(w.b, mt_twist_term(w.ch, w.c1h, w.c1), mt_twist_term(w.ah, w.a1h, w.a1));
+  w.ah = w.a1h;
   w.a1 = mt_seed_step(w.a1, j + 2u);
-  w.c = w.c1;
-  w.c1 = mt_seed_step(w.c1, j - kMtLag + 2u);
-  w.b = mt_seed_step(w.b, j + kMtM - kMtLag + 1u);
+  w.a1h = w.a1 >> 1;
+  w.ch = w.c1h;
+  w.c1 = mt_seed_step(w.c1, near);
+  w.c1h = w.c1 >> 1;
+  w.b = mt_seed_step(w.b, far);
   return g;
 }
 
+// A path that rejects an output would use one output more than it has periods, and every later draw
+// would come from the next output: its lane is flagged instead (one v_cmp whose result is OR-ed into a
+// scalar mask) and the path is left to the generic kernel -- 1e-4 of the paths for the 1127-entry table
+// at 360 periods.  That keeps the loop free of per-lane state: no accept/select, no draw counter.
 template <int kDiv>
 __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
   extern __shared__ __align__(16) float lds_table[];
   for (uint32_t i = threadIdx.x; i < k.table_len; i += kBlock) lds_table[i] = k.table_a[i];
   __syncthreads();
   constexpr bool kExactDiv = kDiv == kDivExact;
-  const uint32_t P = k.n_periods;
+  const uint32_t P = k.n_periods;  // <= ref_windowed_max_outputs()
   const uint32_t n_chunks = (k.n_paths + kBlock - 1u) / kBlock;  // n_paths <= 2^31
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t i = chunk * kBlock + threadIdx.x;
-    const bool active = i < k.n_paths;
     MtWindow w;
     w.seed = k.seed0 + i;
     w.x397 = w.seed;
     for (uint32_t idx = 1; idx <= kMtM; ++idx) w.x397 = mt_seed_step(w.x397, idx);
-    w.a = w.seed;
-    w.a1 = mt_seed_step(w.seed, 1u);
-    w.b = w.x397;
-    w.c = w.c1 = 0u;
+    window_enter_a(w);
+    w.ch = w.c1 = w.c1h = 0u;
     float total = k.initial_capital;
-    uint32_t need = P;  // lanes past the end run a path too (nothing of it is stored): `need` stays a plain count
-    bool left = false;
-    auto check = [&]() {  // kDivChecked: the window of divide_kind() (smmc_capi.cpp), at least every 8 periods
-      if constexpr (kDiv == kDivChecked) left |= !(total > k.chk_lo && total < k.chk_hi);
+    // lanes whose path rejected an output or left the checked divide's window: a scalar mask (v_cmp
+    // writes the wave's 64 results to an SGPR pair, the OR is scalar: one VALU instruction per period)
+    uint64_t redo_mask = 0;
+    auto period = [&](uint32_t g, uint32_t j) {
+      const uint32_t y = mt_temper(g);
+      const uint64_t prod = static_cast<uint64_t>(y) * k.table_len;
+      redo_mask |= __ballot(static_cast<uint32_t>(prod) < k.reject_below);
+      total = compound<kExactDiv>(total, lds_table[static_cast<uint32_t>(prod >> 32)]);
+      if constexpr (kDiv == kDivChecked) {  // the window of divide_kind() (smmc_capi.cpp): at least every 8 periods
+        if ((j & 7u) == 7u) redo_mask |= __ballot(!(total > k.chk_lo && total < k.chk_hi));
+      }
     };
+    // four outputs per trip, written out (a loop holding a ballot is not unrolled with a remainder)
     uint32_t j = 0;
     const uint32_t first = P < kMtLag ? P : kMtLag;
-    for (; j < first; ++j) {
-      offer<kExactDiv, true>(k, lds_table, window_next_a(w, j), total, need);
-      if ((j & 7u) == 7u) check();
+    for (; j + 4u <= first; j += 4u) {
+      uint32_t far = j + kMtM + 1u;
+      asm("" : "+s"(far));  // a scalar of its own (see window_next_a)
+#pragma unroll
+      for (uint32_t t = 0; t < 4u; ++t) period(window_next_a(w, j + t, far + t), j + t);
     }
+    for (; j < first; ++j) period(window_next_a(w, j, j + kMtM + 1u), j);
     if (P > kMtLag) {
       window_enter_b(w);
-      for (; j < P; ++j) {
-        offer<kExactDiv, true>(k, lds_table, window_next_b(w, j), total, need);
-        if ((j & 7u) == 7u) check();
+      for (; j + 4u <= P; j += 4u) {
+        uint32_t near = j - kMtLag + 2u, far = j + kMtM - kMtLag + 1u;
+        asm("" : "+s"(near));
+        asm("" : "+s"(far));
+#pragma unroll
+        for (uint32_t t = 0; t < 4u; ++t) period(window_next_b(w, j + t, near + t, far + t), j + t);
       }
+      for (; j < P; ++j) period(window_next_b(w, j, j - kMtLag + 2u, j + kMtM - kMtLag + 1u), j);
     }
-    // rejected draws are made up from the outputs that follow (rare; wave-uniform trip count)
-    while (j < k.max_outputs && __any(need != 0u)) {
-      uint32_t g;
-      if (j < kMtLag) {
-        g = window_next_a(w, j);
-      } else {
-        if (j == kMtLag) window_enter_b(w);
-        g = window_next_b(w, j);
-      }
-      offer<kExactDiv, false>(k, lds_table, g, total, need);
-      check();
-      ++j;
-    }
-    if (active) {
-      if (need != 0u || left) {
+    if (i < k.n_paths) {
+      if ((redo_mask >> (threadIdx.x & 63u)) & 1u) {
         k.redo_list[atomicAdd(k.redo_count, 1u)] = i;  // finished by ref_generic_kernel with the IEEE divide
       } else {
         k.d_final[i] = total;
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
     }
     float total = k.initial_capital;
     uint32_t need = active ? P : 0u;
-    uint32_t xn = seed;  // x[j]
+    uint32_t xnh = seed >> 1;  // x[j] >> 1
     uint32_t s = 0;      // j mod 624; batches of 8 never straddle the wrap (624 = 8 x 78)
     auto wrap = [](uint32_t v) { return v >= kMtN ? v - kMtN : v; };
     while (__any(need != 0u)) {
@@ -211,10 +229,11 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
       }
 #pragma unroll
       for (uint32_t t = 0; t < 8; ++t) {
-        const uint32_t g = m[t] ^ mt_twist_term(xn, n1[t]);
+        const uint32_t n1h = n1[t] >> 1;
+        const uint32_t g = m[t] ^ mt_twist_term(xnh, n1h, n1[t]);
         W[static_cast<size_t>(s + t) * L] = g;  // x[j + t + 624] takes the place of x[j + t]
-        offer<kExactDiv, false>(k, lds_table, g, total, need);
-        xn = n1[t];
+        offer<kExactDiv>(k, lds_table, g, total, need);
+        xnh = n1h;
       }
       s = wrap(s + 8u);
     }

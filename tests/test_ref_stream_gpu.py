@@ -82,8 +82,8 @@ def test_baseline_config0_size_matches_oracle_engine_r(eng, oracle, table):
     assert np.array_equal(st2.hist, st.hist) and st2.below == st.below and st2.sum == st.sum
 
 
-# 226/227/228: the windowed kernel's second stretch begins at output 227; 438 is the last length it takes
-# with the default slack of 16 outputs, from 439 on the generic kernel runs; 624/625: the state wraps
+# 226/227/228: the windowed kernel's second stretch begins at output 227; 454 is the last length it takes,
+# from 455 on the generic kernel runs; 624/625: the state wraps
 @pytest.mark.parametrize("p", [0, 1, 2, 7, 8, 9, 226, 227, 228, 229, 360, 437, 438, 439, 453, 454, 455, 623, 624, 625, 1000, 1300])
 def test_every_length_both_kernels(eng, oracle, table, p):
     n, seed0 = 2000 + 77, 4000000000  # ragged; seeds wrap past 2^32 inside the launch window
@@ -109,23 +109,22 @@ def test_forced_kernels_and_divides_agree(table, oracle, monkeypatch, kernel, ex
 
 
 def test_rejections_take_the_redo_path(table, oracle, monkeypatch):
-    """With no slack a path that rejects one generator output cannot finish in the windowed kernel: it goes
-    on the redo list and the generic kernel finishes it.  T = 12289 rejects 2.1e-6 of the outputs: a few
-    hundred of the 4e5 paths."""
+    """The windowed kernel only flags a path that rejects a generator output: it goes on the redo list and
+    the generic kernel finishes it.  T = 12289 rejects 2.1e-6 of the outputs: a few hundred of the 4e5
+    paths; every one of them must come back with the oracle's bits, whichever kernel is forced."""
     rng = np.random.default_rng(5)
     big = rng.normal(0.6, 4.3, 12289).astype(np.float32)
     threshold = (2 ** 32 - big.size) % big.size
     n, p, seed0 = 400_000, 360, 31337
-    # how many paths reject at least once (from the oracle's index stream, independent of the engine)
     want, _ = oracle.ref_mc_simulations(n, p, 1000.0, big, seed0)
-    expect_rejecting = n * (1.0 - (1.0 - threshold / 2.0 ** 32) ** p)
+    expect_rejecting = n * (1.0 - (1.0 - threshold / 2.0 ** 32) ** p)  # paths with at least one rejected output
     assert 50 < expect_rejecting < 5000
-    for slack in (0, 1, 16):
-        e = _engine(big, monkeypatch, SMMC_REF_SLACK=slack)
+    for kernel in ("auto", "windowed", "generic"):
+        e = _engine(big, monkeypatch, SMMC_REF_KERNEL=kernel)
         try:
             r = e.simulate(_sim(n, p, seed0))
             e.sync()
-            assert np.array_equal(_bits(r.final.cpu().numpy()), _bits(want)), slack
+            assert np.array_equal(_bits(r.final.cpu().numpy()), _bits(want)), kernel
         finally:
             e.close()
 
