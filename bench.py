@@ -56,6 +56,17 @@ VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock 
 # tools/isa_loop_count.py (tests/test_measurement_cpu.py asserts these equal the built library's).
 VALU_INSTS_PER_STEP = {"gaussian": 70 / 4, "table": 84 / 8}  # Gaussian: counter stream v3 (v2: 122 / 4)
 VALU_CHECK_PER_STEP = {"gaussian": 2 / 4, "table": 2 / 8}  # the range-checked divide: two compares per Philox block
+# --stream ref (the reference CPU engine's per-path mt19937 stream, ref_windowed_kernel): VALU instructions per
+# step of the 397-step seed run-up, per output below output 227 and per output from 227 on (same ISA test)
+REF_VALU = {"runup_step": 34 / 8, "output_lo": 108 / 4, "output_hi": 142 / 4}
+REF_WINDOW = (397, 227, 454)  # run-up steps, first output of the second stretch, longest path of the windowed kernel
+
+
+def ref_valu_per_path(periods):
+    """VALU instructions ref_windowed_kernel spends on one path of `periods` <= 454 periods."""
+    runup, split, _ = REF_WINDOW
+    return (runup * REF_VALU["runup_step"] + min(periods, split) * REF_VALU["output_lo"]
+            + max(periods - split, 0) * REF_VALU["output_hi"])
 # HBM bytes per launch measured by the round's rocprofv3 PMC passes (tools/pmc_traffic.py writes it)
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
@@ -142,6 +153,32 @@ def cpu_baseline(table, budget_s=12.0, n_periods=N_PERIODS):
            "sample": f"{n} paths x {n_periods} periods, table mode (T={table.size}), oracle engine R "
                      f"(per-path mt19937 + Lemire + update_fund, OpenMP dynamic blocks of 1000, deterministic "
                      f"seeds: no per-path std::random_device), {dt:.1f} s; single thread: {n1} paths, {dt1:.1f} s"}
+    # BASELINE configs[0] as written -- "Gaussian returns, single-thread CPU reference (fixed seed)": the
+    # reference's Gaussian demo path (std::default_random_engine + std::normal_distribution<float>(0.5, 0.83333),
+    # src/simulations.cpp:41-67) beside the GPU's Gaussian headline; one thread, then all of them
+    try:
+        ng, dtg = 100_000, 0.0
+        while True:
+            t0 = time.perf_counter()
+            O.asref_gaussian_mc(ng, n_periods, 1000.0, 0.5, 0.83333, 12345, n_threads=1)
+            dtg = time.perf_counter() - t0
+            if dtg >= 2.0 or ng >= 50_000_000:
+                break
+            ng = int(ng * min(max(3.0 / max(dtg, 1e-3), 1.5), 20.0))
+            ng -= ng % 1000
+        nga = max(1000, int(ng / dtg * 3.0 * used))
+        nga -= nga % 1000
+        t0 = time.perf_counter()
+        O.asref_gaussian_mc(nga, n_periods, 1000.0, 0.5, 0.83333, 12345, n_threads=threads)
+        dtga = time.perf_counter() - t0
+        out["gaussian_single_thread_value"] = ng / dtg
+        out["gaussian_value"] = nga / dtga
+        out["gaussian_sample"] = (f"{ng} paths x {n_periods} periods on 1 thread, {dtg:.1f} s; {nga} paths on {used} threads, "
+                                  f"{dtga:.1f} s: std::default_random_engine + std::normal_distribution<float>(0.5, 0.83333) "
+                                  f"per path, fixed seed, update_fund (oracle/asref_cpu.cpp: BASELINE configs[0] as written)")
+    except Exception as ex:
+        out["gaussian_single_thread_value"] = out["gaussian_value"] = None
+        out["gaussian_sample"] = f"unavailable: {ex}"
     # variant (i) of SURVEY 8d: as the reference does it, a fresh std::random_device seeding a fresh
     # mt19937 for EVERY path (src/simulations.cpp:245-247) -- set-up dominated and OS dependent
     try:
@@ -213,6 +250,15 @@ def pmc_traffic(mode, n, periods, outputs):
     rec = table.get(f"{mode}|{n}|{periods}|{outputs}")
     if not rec:
         return None, None
+    # the figure belongs to the build that was profiled: kernel sources + compiler flags must be the ones
+    # in this tree (the compiled ISA is compared by tests/test_measurement_cpu.py)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_loop_count as I
+        if rec.get("source_sha256") != I.source_digest():
+            return None, f"stale: the kernel sources changed since {rec.get('source')}"
+    except Exception as ex:
+        return None, f"unverified: {ex}"
     return float(rec["bytes"]), rec.get("source")
 
 
@@ -334,6 +380,10 @@ def main():
                     help="all = final values + block means + statistics (configs[1]); final = final values only; "
                          "stats = statistics only (no per-path HBM write); host = final values into pinned host "
                          "memory through the chunked side-stream pipeline (configs[4])")
+    ap.add_argument("--stream", choices=["3", "2", "ref"], default="3",
+                    help="3 / 2: the build's Philox counter streams (3 is the default and the headline); ref: the "
+                         "reference CPU engine's own stream on the device -- per-path mt19937 + libstdc++ Lemire map "
+                         "(src/simulations.cpp:240-252), table mode")
     ap.add_argument("--rehearse-rccl", action="store_true",
                     help="with --gpus 1: still initialise the process group (one rank) and run every collective "
                          "of the N > 1 path -- barrier, the record all_gather, the max-reduce of the time -- so that "
@@ -358,7 +408,9 @@ def main():
         return launch_check(args, world, rank)
 
     preset = CONFIGS[args.config]
-    mode_name = args.mode or preset["mode"]
+    mode_name = args.mode or ("table" if args.stream == "ref" else preset["mode"])
+    if args.stream == "ref" and mode_name != "table":
+        raise SystemExit("--stream ref is the reference's table-draw engine: --mode table")
     periods = args.periods if args.periods is not None else preset["periods"]
     outputs = args.outputs or preset["outputs"]
     total_paths, per_gpu = preset["total_paths"], preset["paths_per_gpu"]
@@ -367,7 +419,7 @@ def main():
     elif args.paths_per_gpu is not None:
         total_paths, per_gpu = None, args.paths_per_gpu
     is_preset = (args.mode is None and args.periods is None and args.outputs is None and args.total_paths is None
-                 and args.paths_per_gpu is None)
+                 and args.paths_per_gpu is None and args.stream == "3")
 
     import torch
     import torch.distributed as dist
@@ -406,7 +458,8 @@ def main():
         first, n = rank * per_gpu, per_gpu
         n_all = per_gpu * world
     sim = S.Engine.make_sim(n, periods, mode, SEED, first_path=first, initial_capital=1000.0,
-                            gauss_mean=0.5, gauss_std=0.83333, n_bins=100, hist_lo=0.0, hist_hi=20000.0)
+                            gauss_mean=0.5, gauss_std=0.83333, n_bins=100, hist_lo=0.0, hist_hi=20000.0,
+                            stream="ref" if args.stream == "ref" else int(args.stream))
     to_host = outputs == "host"
     want_final = outputs in ("all", "final")
     want_chunks = outputs == "all"
@@ -482,10 +535,18 @@ def main():
         writes_final = want_final or to_host
         bytes_per_launch = 4.0 * paths_per_launch if writes_final else 0.0
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(mode_name, n, periods, outputs)
+        traffic, traffic_src = pmc_traffic(mode_name if args.stream != "ref" else "ref", n, periods, outputs)
         insts = VALU_INSTS_PER_STEP[mode_name]
         kind = eng.divide_kind(sim)
-        if kind == 2:  # checked
+        kernel_name = "paths_kernel"
+        if args.stream == "ref":
+            windowed = periods <= REF_WINDOW[2]
+            kernel_name = "ref_windowed_kernel" if windowed else "ref_generic_kernel"
+            # the generic kernel (longer paths) keeps its generator states in memory and is not priced here
+            insts = ref_valu_per_path(periods) / periods if (windowed and kind == 0 and periods) else None
+        elif args.stream == "2":
+            insts = None  # round 1's stream: counts in DESIGN.md section 5, not tracked by the ISA test
+        elif kind == 2:  # checked
             insts = insts + VALU_CHECK_PER_STEP[mode_name]
         elif kind == 1:  # IEEE divide: not counted
             insts = None
@@ -499,7 +560,9 @@ def main():
         workload = (preset["name"] if is_preset else
                     f"{mode_name} returns, {periods} periods x "
                     + (f"{total_paths:.3g} paths in total" if total_paths is not None else f"{per_gpu:.3g} paths per GPU")
-                    + f", outputs={outputs}")
+                    + f", outputs={outputs}"
+                    + (", the reference CPU engine's own stream (per-path mt19937 + libstdc++ Lemire map)"
+                       if args.stream == "ref" else f", counter stream v{args.stream}"))
         out = {
             "metric": "simulated paths/sec at N=360 periods" if periods == 360
                       else f"simulated paths/sec at N={periods} periods",
@@ -513,11 +576,12 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "baseline_config": args.config if is_preset else None,
                        "paths_rank0": n, "paths_all_ranks": n_all, "n_periods": periods, "mode": mode_name,
-                       "outputs": outputs, "seed": hex(SEED), "divide": ("fast", "exact", "checked")[kind],
+                       "outputs": outputs, "seed": hex(SEED), "stream": args.stream,
+                       "divide": ("fast", "exact", "checked")[kind],
                        "parallelism": par},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "paths_kernel", "kernel_ms": k_avg_s * 1e3, "launches": launches,
+                         "kernel": kernel_name, "kernel_ms": k_avg_s * 1e3, "launches": launches,
                          "bytes_per_launch": bytes_per_launch,
                          "note": "VALU-bound kernel: 4 B of HBM traffic per path by construction; see valu"},
             "valu": {"bound": "valu-issue", "achieved": valu_ach, "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s",

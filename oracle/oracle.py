@@ -187,11 +187,7 @@ def ref_mc_simulations(n_paths, n_periods, initial_capital, table, seed0, n_thre
 _asref = None
 
 
-def asref_mc_simulations(n_paths, n_periods, initial_capital, table, n_threads=0, fixed_seed0=None):
-    """The reference's CPU loop as it really runs (src/simulations.cpp:240-252): a fresh
-    std::random_device + mt19937 per path, real libstdc++ classes (oracle/asref_cpu.cpp).  Not
-    reproducible unless fixed_seed0 is given, in which case it must equal engine (R).
-    Returns (final_values, threads_used)."""
+def _asref_lib():
     global _asref
     if _asref is None:
         so = os.path.join(_HERE, "libsmmc_asref.so")
@@ -202,7 +198,29 @@ def asref_mc_simulations(n_paths, n_periods, initial_capital, table, n_threads=0
         L.orc_asref_mc_simulations.restype = C.c_int
         L.orc_asref_mc_simulations.argtypes = [C.c_int64, C.c_uint32, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p,
                                                C.c_int, C.c_int, C.c_uint32]
+        L.orc_asref_gaussian_mc.restype = C.c_int
+        L.orc_asref_gaussian_mc.argtypes = [C.c_int64, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32,
+                                            C.c_void_p, C.c_int]
         _asref = L
+    return _asref
+
+
+def asref_gaussian_mc(n_paths, n_periods, initial_capital, mean, std, seed0, n_threads=0):
+    """BASELINE configs[0] as written: the reference's Gaussian demo path (std::default_random_engine +
+    std::normal_distribution<float>, src/simulations.cpp:41-67) with a fixed seed, real libstdc++
+    classes (oracle/asref_cpu.cpp).  Returns (final_values, threads_used)."""
+    out = np.empty(n_paths, dtype=np.float32)
+    used = _asref_lib().orc_asref_gaussian_mc(n_paths, n_periods, float(initial_capital), float(mean), float(std),
+                                              C.c_uint32(seed0 & 0xFFFFFFFF), out.ctypes.data_as(C.c_void_p), n_threads)
+    return out, used
+
+
+def asref_mc_simulations(n_paths, n_periods, initial_capital, table, n_threads=0, fixed_seed0=None):
+    """The reference's CPU loop as it really runs (src/simulations.cpp:240-252): a fresh
+    std::random_device + mt19937 per path, real libstdc++ classes (oracle/asref_cpu.cpp).  Not
+    reproducible unless fixed_seed0 is given, in which case it must equal engine (R).
+    Returns (final_values, threads_used)."""
+    _asref_lib()
     t = _f32(table)
     out = np.empty(n_paths, dtype=np.float32)
     used = _asref.orc_asref_mc_simulations(n_paths, n_periods, float(initial_capital), t.ctypes.data_as(C.c_void_p),

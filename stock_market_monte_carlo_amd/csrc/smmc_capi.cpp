@@ -41,6 +41,18 @@ int fail(int code, const char *fmt, ...) {
                   __FILE__, __LINE__);                                                         \
   } while (0)
 
+// Inside an open timing pair (timing_begin .. timing_end): a failure closes the pair before it returns,
+// so that smmc_engine_kernel_ms never reads a start event without its stop.
+#define SMMC_HIP_TIMED(e, call)                                                                \
+  do {                                                                                         \
+    hipError_t err__ = (call);                                                                 \
+    if (err__ != hipSuccess) {                                                                 \
+      (void)timing_end(e);                                                                     \
+      return fail(SMMC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__),     \
+                  __FILE__, __LINE__);                                                         \
+    }                                                                                          \
+  } while (0)
+
 // Makes `device` current for the scope and restores the caller's device after.
 struct DeviceGuard {
   int prev = -1;
@@ -60,7 +72,7 @@ struct DeviceGuard {
 // 1e8 x 360 table paths: 13.1 ms at 6 per CU, 12.6 at 8, 11.7 at 16, 11.1 at 64..256.
 constexpr uint32_t kBlocksPerCU = 64;
 constexpr uint64_t kHostChunkPaths = 1ull << 24;     // simulate_to_host: 64 MiB of floats per chunk
-constexpr uint64_t kProgressChunkMin = 1ull << 20;   // ... and at least this many when progress is polled
+constexpr uint64_t kProgressChunkMin = 1ull << 16;   // ... and at least this many when progress is polled
 
 }  // namespace
 
@@ -283,7 +295,11 @@ int values_stats_enqueue(smmc_engine *e, const float *d_values, uint64_t n, floa
   if (n) {
     int rc = timed ? timing_begin(e) : SMMC_OK;
     if (rc) return rc;
-    SMMC_HIP(smmc::launch_values_stats(a, grid, e->stream));
+    const hipError_t err = smmc::launch_values_stats(a, grid, e->stream);
+    if (err != hipSuccess) {
+      if (timed) (void)timing_end(e);
+      return fail(SMMC_ERR_HIP, "launch_values_stats failed: %s", hipGetErrorString(err));
+    }
     rc = timed ? timing_end(e) : SMMC_OK;
     if (rc) return rc;
   }
@@ -361,13 +377,13 @@ int enqueue_ref_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, fl
       if (windowed) {
         a.redo_count = e->d_ref_redo;
         a.redo_list = e->d_ref_redo + 4;
-        SMMC_HIP(hipMemsetAsync(e->d_ref_redo, 0, sizeof(uint32_t), e->stream));
-        SMMC_HIP(smmc::launch_ref_windowed(a, div, grid, e->stream));
-        SMMC_HIP(smmc::launch_ref_generic(a, true, kRefRedoGrid, e->stream));
+        SMMC_HIP_TIMED(e, hipMemsetAsync(e->d_ref_redo, 0, sizeof(uint32_t), e->stream));
+        SMMC_HIP_TIMED(e, smmc::launch_ref_windowed(a, div, grid, e->stream));
+        SMMC_HIP_TIMED(e, smmc::launch_ref_generic(a, true, kRefRedoGrid, e->stream));
       } else {
         a.redo_count = nullptr;
         a.redo_list = nullptr;
-        SMMC_HIP(smmc::launch_ref_generic(a, div != SMMC_DIV_FAST, std::min(grid, full_grid), e->stream));
+        SMMC_HIP_TIMED(e, smmc::launch_ref_generic(a, div != SMMC_DIV_FAST, std::min(grid, full_grid), e->stream));
       }
     }
     rc = timing_end(e);
@@ -406,7 +422,11 @@ int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float 
     int rc = timing_begin(e);
     if (rc) return rc;
     const int div = divide_kind(e, s, true, &a.chk_lo, &a.chk_hi);
-    SMMC_HIP(smmc::launch_paths(a, div, grid, lds, e->stream));
+    const hipError_t err = smmc::launch_paths(a, div, grid, lds, e->stream);
+    if (err != hipSuccess) {
+      (void)timing_end(e);
+      return fail(SMMC_ERR_HIP, "launch_paths failed: %s", hipGetErrorString(err));
+    }
     rc = timing_end(e);
     if (rc) return rc;
   }
@@ -481,7 +501,8 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
   }
   if (const char *env = std::getenv("SMMC_HOST_CHUNK_PATHS")) {  // tuning/test knob, results do not depend on it
     const long long v = std::strtoll(env, nullptr, 10);
-    if (v >= smmc::kBlock) e->host_chunk_paths = static_cast<uint64_t>(v) / smmc::kBlock * smmc::kBlock;
+    if (v >= 1024) e->host_chunk_paths = static_cast<uint64_t>(v) / 1024 * 1024;
+    else if (v >= smmc::kBlock) e->host_chunk_paths = static_cast<uint64_t>(v) / smmc::kBlock * smmc::kBlock;  // tests
   }
   if (const char *env = std::getenv("SMMC_PIN_HOST")) {  // see smmc_engine_simulate_to_host
     if (!std::strcmp(env, "1") || !std::strcmp(env, "whole")) e->pin_policy = 1;
@@ -680,8 +701,49 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     if (!std::strcmp(env, "comb")) comb = comb_fits && comb_waves >= 1;
   }
   const uint64_t n_comb = comb ? n_super * 2048u : 0u;
+  // Everything that can fail is decided BEFORE the first launch and before the timing pair opens
+  // (a failing tile set-up used to leave the comb part written and a start event without its stop).
+  // Tile form (the rows the comb form does not take): tuning knobs, results do not depend on them:
+  // columns per LDS tile (16 | 32), waves per workgroup, workgroups per CU.  Defaults measured with
+  // tools/kd_ab.py: 32 columns (16 writes half lines); table mode 4 waves, three workgroups per CU (8 or
+  // 12 waves 1-5 % slower, 3 / 5 / 6 waves -- SIMDs unevenly filled -- 5-25 % slower); Gaussian mode,
+  // where the Box-Muller tables take 18.9 KB of every workgroup's LDS, one 12-wave workgroup per CU
+  // (2-15 % faster than two of 4); grid = what is resident (a wave strides over its 64-path chunks).
+  int tile = 32, tile_waves = 0;
+  uint32_t tile_grid = 0;
+  if (n_comb < sim->n_paths) {
+    const uint32_t tl = sim->mode == SMMC_MODE_TABLE ? e->table_len : 0u;
+    const int strm = (sim->flags & SMMC_FLAG_STREAM_V2) ? 2 : 3;
+    if (const char *env = std::getenv("SMMC_KEEPDATA_TILE")) {
+      const long v = std::strtol(env, nullptr, 10);
+      if (v == 16 || v == 32) tile = static_cast<int>(v);
+    }
+    const size_t lds_cu = 160u * 1024u;
+    const size_t fixed = smmc::keepdata_lds_bytes(tl, tile, 0, strm);
+    const size_t per_wave = smmc::keepdata_lds_bytes(tl, tile, 1, strm) - fixed;
+    const int fit = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 12)) : 0;
+    if (fit < 1) return fail(SMMC_ERR_INVALID, "keepdata: the table leaves no LDS for a tile");
+    tile_waves = sim->mode == SMMC_MODE_TABLE ? std::min(fit, 4) : (fit >= 12 ? 12 : fit >= 8 ? 8 : std::min(fit, 4));
+    if (const char *env = std::getenv("SMMC_KEEPDATA_WAVES")) {
+      const long v = std::strtol(env, nullptr, 10);
+      if (v >= 1 && v <= fit) tile_waves = static_cast<int>(v);
+    }
+    const size_t lds = smmc::keepdata_lds_bytes(tl, tile, tile_waves, strm);
+    const uint64_t n_wave_chunks = (sim->n_paths - n_comb + 63) / 64;
+    const uint32_t resident = static_cast<uint32_t>(std::max<size_t>(lds_cu / lds, 1));
+    const uint32_t per_cu = e->keepdata_blocks_per_cu ? e->keepdata_blocks_per_cu : resident;
+    tile_grid = static_cast<uint32_t>(
+        std::min<uint64_t>((n_wave_chunks + tile_waves - 1) / tile_waves, static_cast<uint64_t>(e->compute_units) * per_cu));
+  }
+  if (comb && !e->d_work_counter)
+    SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_work_counter), sizeof(unsigned long long)));
   rc = timing_begin(e);
   if (rc) return rc;
+  // from here on a failure closes the timing pair before it returns
+  auto bail = [&](hipError_t err, const char *what) {
+    (void)timing_end(e);
+    return fail(SMMC_ERR_HIP, "%s failed: %s", what, hipGetErrorString(err));
+  };
   if (comb) {
     smmc::KernelArgs a = make_args(e, sim);
     a.d_traj = d_traj;
@@ -707,9 +769,9 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     if (const char *env = std::getenv("SMMC_KEEPDATA_COMB_ILP")) {  // tuning knob
       if (!std::strcmp(env, "1")) per_step = 1;
     }
-    if (!e->d_work_counter) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_work_counter), sizeof(unsigned long long)));
-    SMMC_HIP(smmc::launch_keepdata_comb(a, exact_div, per_step, k_rows, n_wave_chunks, sim->n_paths, waves, cgrid,
-                                        e->d_work_counter, e->stream));
+    const hipError_t err = smmc::launch_keepdata_comb(a, exact_div, per_step, k_rows, n_wave_chunks, sim->n_paths, waves, cgrid,
+                                                      e->d_work_counter, e->stream);
+    if (err != hipSuccess) return bail(err, "launch_keepdata_comb");
   }
   if (n_comb < sim->n_paths) {
     smmc_sim rest = *sim;
@@ -718,38 +780,13 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     smmc::KernelArgs a = make_args(e, &rest);
     a.d_traj = d_traj + n_comb * row_len;
     a.d_final = (d_final && !comb) ? d_final : nullptr;
-    // tuning knobs, results do not depend on them: columns per LDS tile (16 | 32), waves per
-    // workgroup, workgroups per CU.  Defaults measured with tools/kd_ab.py: 32 columns (16 writes
-    // half lines); table mode 4 waves, three workgroups per CU (8 or 12 waves 1-5 % slower, 3 / 5 /
-    // 6 waves -- SIMDs unevenly filled -- 5-25 % slower); Gaussian mode, where the Box-Muller tables
-    // take 18.9 KB of every workgroup's LDS, one 12-wave workgroup per CU (2-15 % faster than two of
-    // 4); grid = what is resident (a wave strides over its 64-path chunks).
-    int tile = 32;
-    if (const char *env = std::getenv("SMMC_KEEPDATA_TILE")) {
-      const long v = std::strtol(env, nullptr, 10);
-      if (v == 16 || v == 32) tile = static_cast<int>(v);
-    }
-    const size_t lds_cu = 160u * 1024u;
-    const size_t fixed = smmc::keepdata_lds_bytes(a.table_len, tile, 0, a.stream);
-    const size_t per_wave = smmc::keepdata_lds_bytes(a.table_len, tile, 1, a.stream) - fixed;
-    const int fit = fixed < lds_cu ? static_cast<int>(std::min<size_t>((lds_cu - fixed) / per_wave, 12)) : 0;
-    if (fit < 1) return fail(SMMC_ERR_INVALID, "keepdata: the table leaves no LDS for a tile");
-    int waves = sim->mode == SMMC_MODE_TABLE ? std::min(fit, 4) : (fit >= 12 ? 12 : fit >= 8 ? 8 : std::min(fit, 4));
-    if (const char *env = std::getenv("SMMC_KEEPDATA_WAVES")) {
-      const long v = std::strtol(env, nullptr, 10);
-      if (v >= 1 && v <= fit) waves = static_cast<int>(v);
-    }
-    const size_t lds = smmc::keepdata_lds_bytes(a.table_len, tile, waves, a.stream);
-    const uint64_t n_wave_chunks = (rest.n_paths + 63) / 64;
-    const uint32_t resident = static_cast<uint32_t>(std::max<size_t>(lds_cu / lds, 1));
-    const uint32_t per_cu = e->keepdata_blocks_per_cu ? e->keepdata_blocks_per_cu : resident;
-    const uint32_t kgrid = static_cast<uint32_t>(
-        std::min<uint64_t>((n_wave_chunks + waves - 1) / waves, static_cast<uint64_t>(e->compute_units) * per_cu));
-    SMMC_HIP(smmc::launch_keepdata(a, exact_div, tile, waves, kgrid, e->stream));
+    const hipError_t err = smmc::launch_keepdata(a, exact_div, tile, tile_waves, tile_grid, e->stream);
+    if (err != hipSuccess) return bail(err, "launch_keepdata");
   }
   if (comb && d_final) {  // the comb form leaves the final values to a gather of the last column
     const uint32_t fgrid = static_cast<uint32_t>(std::min<uint64_t>((sim->n_paths + smmc::kBlock - 1) / smmc::kBlock, e->max_grid));
-    SMMC_HIP(smmc::launch_final_column(d_traj, sim->n_paths, static_cast<uint32_t>(row_len), d_final, fgrid, e->stream));
+    const hipError_t err = smmc::launch_final_column(d_traj, sim->n_paths, static_cast<uint32_t>(row_len), d_final, fgrid, e->stream);
+    if (err != hipSuccess) return bail(err, "launch_final_column");
   }
   return timing_end(e);
 }
@@ -806,12 +843,15 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
   const uint64_t n = sim->n_paths;
   const bool polled = progress != nullptr || e->progress_fn != nullptr;
-  // chunk: a multiple of 256 paths.  64 MiB of floats by default; when a caller polls the progress
-  // counter (the reference advances it every 1000 paths, src/simulations.cpp:254, and its GUIs redraw
-  // from it, examples/visualize_returns_cpu_v2.cpp:360-376) about 16 steps per run, at least 2^20 paths
+  // chunk: a multiple of 1024 paths (4 KiB of floats: chunks of a page-aligned buffer do not share
+  // pages).  64 MiB of floats by default; when a caller polls the progress counter (the reference
+  // advances it every 1000 paths, src/simulations.cpp:254, and its GUIs redraw from it,
+  // examples/visualize_returns_cpu_v2.cpp:360-376) about 16 steps per run, at least 2^16 paths -- the
+  // 1e6 paths of BASELINE configs[0] advance in 16 steps (a 2^16-path launch still fills the chip:
+  // 256 workgroups)
   uint64_t chunk_max = e->host_chunk_paths;
   if (polled && e->host_chunk_paths == kHostChunkPaths) {
-    const uint64_t sixteenth = (n / 16 + smmc::kBlock - 1) / smmc::kBlock * smmc::kBlock;
+    const uint64_t sixteenth = (n / 16 + 1023) / 1024 * 1024;
     chunk_max = std::min<uint64_t>(kHostChunkPaths, std::max<uint64_t>(kProgressChunkMin, sixteenth));
   }
   const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), chunk_max);
@@ -1022,7 +1062,7 @@ int smmc_engine_order_statistics(smmc_engine *e, const float *d_values, uint64_t
     SMMC_HIP(hipMemsetAsync(e->d_radix_hist, 0, hist_bytes, e->stream));
     int rc = timing_begin(e);
     if (rc) return rc;
-    SMMC_HIP(smmc::launch_radix_hist(d_values, n, pass, n_ranks, e->d_select, e->d_radix_hist, grid, e->stream));
+    SMMC_HIP_TIMED(e, smmc::launch_radix_hist(d_values, n, pass, n_ranks, e->d_select, e->d_radix_hist, grid, e->stream));
     rc = timing_end(e);
     if (rc) return rc;
     SMMC_HIP(smmc::launch_radix_pick(pass, n_ranks, e->d_select, e->d_radix_hist, e->d_select_out, e->stream));
@@ -1136,8 +1176,19 @@ int smmc_engine_set_stream(smmc_engine *e, void *stream) {
   // work already enqueued keeps its order: the new stream waits for the old one's tail (the
   // engine's workspace -- partials, staging -- is shared between consecutive launches)
   if (!e->ev_order) SMMC_HIP(hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming));
-  SMMC_HIP(hipEventRecord(e->ev_order, e->stream));
-  SMMC_HIP(hipStreamWaitEvent(s, e->ev_order, 0));
+  hipError_t err = hipEventRecord(e->ev_order, e->stream);
+  if (err == hipSuccess) {
+    SMMC_HIP(hipStreamWaitEvent(s, e->ev_order, 0));
+  } else if (!e->own_stream) {
+    // The stream the engine was bound to is not the engine's: the caller may have destroyed it since
+    // (a bound stream has to outlive the NEXT set_stream only if work is still pending on it).  The
+    // engine must not be stuck on it: drop the error, let the device drain -- whatever was enqueued
+    // there has then finished, which is the ordering the event would have given -- and move on.
+    (void)hipGetLastError();
+    SMMC_HIP(hipDeviceSynchronize());
+  } else {
+    return fail(SMMC_ERR_HIP, "hipEventRecord on the engine's own stream failed: %s", hipGetErrorString(err));
+  }
   if (e->own_stream) {
     SMMC_HIP(hipStreamSynchronize(e->stream));
     SMMC_HIP(hipStreamDestroy(e->stream));

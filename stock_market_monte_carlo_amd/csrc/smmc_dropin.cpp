@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <filesystem>
 #include <fstream>
@@ -87,9 +88,14 @@ smmc_sim make_sim(int mode, std::uint64_t seed, std::uint64_t first, std::uint64
   s.gauss_mean = 0.5f;
   s.gauss_std = 0.83333f;
   s.below_threshold = capital;
-  // SMMC_STREAM=2: the Gaussian draw of counter stream v2 (round 1) for callers that hold v2 results
-  if (const char *env = std::getenv("SMMC_STREAM"))
+  // SMMC_STREAM=2: counter stream v2 (round 1) for callers that hold v2 results.  SMMC_STREAM=ref: the
+  // reference CPU engine's own stream for the table-draw engines (src/simulations.cpp:240-252: path id draws
+  // from std::mt19937(seed + id) through uniform_int_distribution) -- with SMMC_SEED / fix_seed the final
+  // values are what the reference's mc_simulations computes when its generators are seeded that way
+  if (const char *env = std::getenv("SMMC_STREAM")) {
     if (env[0] == '2' && env[1] == '\0') s.flags |= SMMC_FLAG_STREAM_V2;
+    if (!std::strcmp(env, "ref") && mode == SMMC_MODE_TABLE) s.flags |= SMMC_FLAG_STREAM_REF;
+  }
   return s;
 }
 
@@ -385,6 +391,7 @@ void mc_simulations_keepdata(std::atomic<long> &n_simulations, long max_n_simula
   for (size_t first = 0; first < n; first += slice) {
     const size_t count = std::min(slice, n - first);
     smmc_sim sim = make_sim(SMMC_MODE_TABLE, seed, first, count, n_periods, initial_capital);
+    sim.flags &= ~SMMC_FLAG_STREAM_REF;  // trajectories come from the counter stream only (include/smmc.h)
     check(smmc_engine_simulate_keepdata_to_host(ses.engine, &sim, flat.data(), final_values.data() + first));
     for (size_t i = 0; i < count; ++i) mc_data[first + i].assign(flat.begin() + i * row, flat.begin() + (i + 1) * row);
     n_simulations += static_cast<long>(count);  // src/simulations.cpp:190

@@ -380,8 +380,10 @@ def read_historical_returns(csv_fpath):
     return np.array(vals, dtype=np.float32)
 
 
-def mc_simulations_gpu(max_n_simulations, n_periods, initial_capital, returns, n_gpus=1, seed=None):
+def mc_simulations_gpu(max_n_simulations, n_periods, initial_capital, returns, n_gpus=1, seed=None, stream=3):
     """simulations.h:73-79, src/simulations.cu:661-680: final value of every path (host array).
+    stream: 3 (default) / 2 the build's counter streams; "ref" the reference CPU engine's own stream --
+    path id draws from mt19937(seed + id) through libstdc++'s uniform_int_distribution.
     Paths shard over n_gpus devices of this process by contiguous global id ranges, one host thread
     per shard so that all devices compute and copy at once (the reference's async launcher,
     src/simulations.cu:599-626; ctypes releases the GIL for the duration of the call)."""
@@ -400,7 +402,8 @@ def mc_simulations_gpu(max_n_simulations, n_periods, initial_capital, returns, n
             with torch.cuda.device(devs[g]):
                 e = _engine(devs[g], devs[:g].count(devs[g]))
                 e.set_table(returns)
-                sim = Engine.make_sim(cnt, n_periods, MODE_TABLE, seed, first_path=first, initial_capital=initial_capital)
+                sim = Engine.make_sim(cnt, n_periods, MODE_TABLE, seed, first_path=first, initial_capital=initial_capital,
+                                      stream=stream)
                 e.simulate_to_host(sim, out=out[first:first + cnt])
         except Exception as ex:  # re-raised on the calling thread
             errors.append(ex)
@@ -418,8 +421,11 @@ def mc_simulations_gpu(max_n_simulations, n_periods, initial_capital, returns, n
     return out
 
 
-def mc_simulations(max_n_simulations, n_periods, initial_capital, historical_returns, final_values=None, seed=None):
+def mc_simulations(max_n_simulations, n_periods, initial_capital, historical_returns, final_values=None, seed=None,
+                   stream=3):
     """simulations.h:49-54, src/simulations.cpp:204-266 (the CPU v2 engine), run on the GPU.
+    With stream="ref" and seed=s the result is, bit for bit, what that engine computes when the
+    std::random_device of path id returns s + id (src/simulations.cpp:245-246).
     final_values, if given, must be pre-sized like the reference's caller does
     (examples/benchmark_mc_cpu_v2.cpp:26) and is filled in place."""
     n = int(max_n_simulations)
@@ -427,7 +433,7 @@ def mc_simulations(max_n_simulations, n_periods, initial_capital, historical_ret
         raise ValueError("final_values must be a float32 array of at least max_n_simulations entries")
     e = _engine(0)
     e.set_table(historical_returns)
-    sim = Engine.make_sim(n, n_periods, MODE_TABLE, _seed(seed), initial_capital=initial_capital)
+    sim = Engine.make_sim(n, n_periods, MODE_TABLE, _seed(seed), initial_capital=initial_capital, stream=stream)
     out, _, _ = e.simulate_to_host(sim, out=final_values)
     return out[:n]
 

@@ -79,7 +79,8 @@ def test_cpp_dropin_matches_python_path_and_oracle(built, oracle, table):
 
 
 def _run(prog, *args, env=None):
-    e = dict(os.environ, SMMC_SEED="99", **(env or {}))
+    e = dict(os.environ, SMMC_SEED="99")
+    e.update(env or {})
     return subprocess.run([os.path.join(PKG, "bin", prog), *map(str, args)], cwd=ROOT, env=e, capture_output=True,
                           text=True)
 
@@ -212,3 +213,43 @@ def test_reference_gpu_programs_compiled_unmodified_run_on_the_drop_in(oracle, t
     mb = re.search(r"mean: ([0-9.]+) \| std: ([0-9.]+)", rb.stdout)
     cm, _ = oracle.chunk_mean_var(want)
     assert float(mb.group(1)) == pytest.approx(float(cm.astype(np.float64).mean()), rel=1e-4)
+
+
+def test_reference_stream_through_the_drop_in(built, oracle, table):
+    """SMMC_STREAM=ref: the reference-named entry points draw as the reference's CPU engine does
+    (src/simulations.cpp:240-252: mt19937(seed + id), uniform_int_distribution, update_fund).  The C++
+    check program (mc_simulations_gpu, mc_simulations, reduceBlock under fix_seed(4242)), the reference's
+    own examples/benchmark_mc_gpu.cpp main and the Python mirror all give oracle engine (R)'s numbers."""
+    import stock_market_monte_carlo_amd as S
+    n, p = 20000, 36
+    out = subprocess.check_output([built, str(n), str(p)], cwd=ROOT, env=dict(os.environ, SMMC_STREAM="ref"))
+    d = json.loads(out.decode().strip().splitlines()[-1])
+    want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, 4242)
+    assert d["gpu_hash"] == fnv(want) == d["cpu_hash"] and d["concurrent_ok"]
+    cm, cv = oracle.chunk_mean_var(want)
+    assert d["mean0"] == pytest.approx(float(cm[0]), rel=1e-6) and d["var0"] == pytest.approx(float(cv[0]), rel=1e-5)
+    assert np.array_equal(np.array(d["quart"], dtype=np.float32), oracle.quartiles(want))
+    # trajectories stay on the counter stream (include/smmc.h): keepdata is not affected by SMMC_STREAM=ref
+    keep = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, p, 3000, 4242, table=table))["final"]
+    assert d["rows_ok"] and d["keep_hash"] == fnv(keep)
+    # Python mirror
+    got = S.mc_simulations(n, p, 1000.0, table, seed=4242, stream="ref")
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    got3 = S.mc_simulations_gpu(n + 1, p, 1000.0, table, n_gpus=1, seed=4241, stream="ref")
+    assert np.array_equal(got3[1:].view(np.uint32), want.view(np.uint32))  # path id 1 of seed 4241 is path 0 of 4242
+    # the benchmark program, at BASELINE configs[0] size: mean / std / count of the oracle's final values
+    nb = 1_000_000
+    r = _run("benchmark_mc_cpu_v2", 360, nb, env={"SMMC_STREAM": "ref", "SMMC_SEED": "1000", "SMMC_JSON": "1"})
+    assert r.returncode == 0 and re.search(rf"All {nb} simulation done in", r.stdout), r.stderr
+    if os.path.exists(os.path.join(REF_DIR, "benchmark_mc_gpu")):
+        env = dict(os.environ, SMMC_SEED="1000", SMMC_STREAM="ref", LOCPATH=os.path.join(REF_DIR, "locale"))
+        r = subprocess.run([os.path.join(REF_DIR, "benchmark_mc_gpu"), "1", "360", str(nb)], cwd=ROOT, env=env,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        big, _ = oracle.ref_mc_simulations(nb, 360, 1000.0, table, 1000)
+        m = re.search(r"mean: ([0-9.]+) \| std: ([0-9.]+)", r.stdout)
+        c = re.search(r"count_below 1000.0: ([0-9,]+) \(", r.stdout)
+        w64 = big.astype(np.float64)
+        assert float(m.group(1)) == pytest.approx(w64.mean(), abs=0.006)
+        assert float(m.group(2)) == pytest.approx(w64.std(), rel=1e-4)
+        assert int(c.group(1).replace(",", "")) == int((big < 1000.0).sum())

@@ -34,19 +34,81 @@ def test_valu_instruction_counts_match_the_built_kernels(asm, mode):
     assert c["v_bitop3_b32"] >= 15 and c["v_mad_u64_u32"] >= 16
 
 
+def test_ref_stream_instruction_counts_match_the_built_kernel(tmp_path):
+    """bench.py --stream ref prices ref_windowed_kernel with three counts: per step of the seed run-up, per
+    output below output 227 (two seed chains) and from 227 on (three chains, the earlier output generated
+    again).  Re-derived from the kernel as it compiles now: the two written-out 4-output loops are the two
+    largest innermost loops, the run-up is the 8-step loop of plain seed steps."""
+    import bench
+    import isa_loop_count as I
+    import isa_loops as L
+    asm = I.emit_asm(str(tmp_path / "smmc_ref_kernels.s"), "smmc_ref_kernels.hip")
+    lines = open(asm).read().splitlines()
+    body = L.kernel_body(lines, "ref_windowed_kernelILi0E")
+    found = sorted((L.summary(c)[0], c) for _, c in L.loops(body))
+    (hi, c_hi), (lo, c_lo) = found[-1], found[-2]
+    assert hi == pytest.approx(bench.REF_VALU["output_hi"] * 4) and lo == pytest.approx(bench.REF_VALU["output_lo"] * 4)
+    for c, chains in ((c_lo, 2), (c_hi, 3)):
+        assert c["ds_read_b32"] == 4 and c["v_mul_lo_u32"] == 4 * chains and c["v_mad_u64_u32"] == 4
+        assert c["v_bfi_b32"] == 4 * (chains - 1) and c["v_cmp_gt_u32_e32"] == 4  # the rejection test: one v_cmp
+        assert "v_cndmask_b32_e32" not in c and "v_cndmask_b32_e64" not in c      # no per-lane select in the loop
+    # the run-up: the first innermost loop of the per-chunk loop, eight seed steps per trip (its exit test
+    # sits in the middle of the trip, so it ends at the first unconditional branch back)
+    first = next(i for i, ln in enumerate(body) if "Inner Loop Header: Depth=2" in ln)
+    last = next(i for i in range(first, len(body)) if body[i].split()[:1] == ["s_branch"])
+    trip = [ln.split()[0] for ln in body[first:last] if ln.strip() and ln.strip()[0] not in ";."]
+    assert trip.count("v_mul_lo_u32") == 8
+    assert sum(1 for op in trip if op.startswith("v_")) == pytest.approx(bench.REF_VALU["runup_step"] * 8)
+    assert bench.ref_valu_per_path(360) == pytest.approx(397 * 34 / 8 + 227 * 27 + 133 * 35.5)
+    assert 0 < bench.ref_valu_per_path(0) < bench.ref_valu_per_path(1)
+
+
 def test_pmc_traffic_table_names_its_sources():
     import bench
     table = json.load(open(bench.PMC_TRAFFIC_FILE))
     assert "gaussian|100000000|360|all" in table
     for key, rec in table.items():
         mode, n, periods, outputs = key.split("|")
-        assert mode in ("gaussian", "table") and outputs in ("all", "final", "stats", "host")
+        assert mode in ("gaussian", "table", "ref") and outputs in ("all", "final", "stats", "host")
         src = rec["source"].split(" ")[0]
         assert src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src)), src
         # algorithmic bytes: 4 B per path (+ 8 B per 256-path chunk): traffic must not be below them
         if outputs in ("all", "final"):
             assert rec["bytes"] >= 4.0 * int(n)
             assert rec["bytes"] <= 1.25 * (4.0 + 8.0 / 256.0 * 8) * int(n)  # chunk stats are counted as 32-byte writes
-    b, src = bench.pmc_traffic("gaussian", 100_000_000, 360, "all")
-    assert b and src
     assert bench.pmc_traffic("gaussian", 12345, 360, "all") == (None, None)
+
+
+def test_pmc_traffic_belongs_to_the_kernels_as_they_compile_now(asm, tmp_path):
+    """Every entry of profiles/pmc_traffic.json carries the fingerprint of the kernel that was profiled (its
+    instruction mnemonics in program order) and a digest of the kernel sources + compiler flags.  A kernel
+    change without a new PMC pass fails here; bench.py itself reports `traffic: null` for a stale entry."""
+    import bench
+    import isa_loop_count as I
+    table = json.load(open(bench.PMC_TRAFFIC_FILE))
+    ref_asm = None
+    for key, rec in table.items():
+        mode = key.split("|")[0]
+        src, kernel, variant = I.TRAFFIC_KERNELS[mode]
+        assert rec["kernel"] == kernel + variant
+        path = asm
+        if src != "smmc_kernels.hip":
+            ref_asm = ref_asm or I.emit_asm(str(tmp_path / "ref.s"), src)
+            path = ref_asm
+        assert rec["isa_fingerprint"] == I.fingerprint(path, variant, kernel), (
+            f"{key}: the kernel changed since the PMC pass ({rec['source']}): run tools/profile_r03.sh again")
+        assert rec["source_sha256"] == I.source_digest(), f"{key}: kernel sources or flags changed since the PMC pass"
+    b, src = bench.pmc_traffic("gaussian", 100_000_000, 360, "all")
+    assert b and src and src.startswith("profiles/")
+    # a stale entry is not quoted
+    stale = dict(table)
+    stale["gaussian|100000000|360|all"] = dict(stale["gaussian|100000000|360|all"], source_sha256="0" * 64)
+    p = tmp_path / "stale.json"
+    p.write_text(json.dumps(stale))
+    old = bench.PMC_TRAFFIC_FILE
+    try:
+        bench.PMC_TRAFFIC_FILE = str(p)
+        b, why = bench.pmc_traffic("gaussian", 100_000_000, 360, "all")
+        assert b is None and why.startswith("stale")
+    finally:
+        bench.PMC_TRAFFIC_FILE = old

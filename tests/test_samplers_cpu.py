@@ -64,3 +64,22 @@ def test_sample_returns_gaussian_moments(host_check):
 def test_scalar_functions(host_check, oracle):
     assert host_check["update_fund"] == 1005.0
     assert np.array_equal(np.array(host_check["mu"], dtype=np.float32), oracle.many_updates(1000.0, [1.0, -2.0, 3.5], 3))
+
+
+def test_gaussian_cpu_reference_leg(oracle):
+    """oracle/asref_cpu.cpp orc_asref_gaussian_mc -- BASELINE configs[0] as written (the reference's Gaussian
+    demo path with a fixed seed; timed by bench.py's cpu_baseline): deterministic, independent of the
+    thread count, and its final values have the log-normal law of 360 N(0.5 %, 0.83333 %) months."""
+    a, used = oracle.asref_gaussian_mc(60000, 360, 1000.0, 0.5, 0.83333, 7, n_threads=1)
+    b, used4 = oracle.asref_gaussian_mc(60000, 360, 1000.0, 0.5, 0.83333, 7, n_threads=4)
+    assert used == 1 and used4 == 4 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    c, _ = oracle.asref_gaussian_mc(60000, 360, 1000.0, 0.5, 0.83333, 8, n_threads=4)
+    assert not np.array_equal(a, c) and np.array_equal(a[1:], c[:-1])  # path id of seed 8 is path id + 1 of seed 7
+    # log final = sum of 360 log(1 + r/100), r ~ N(0.5, 0.83333): mean and variance by the delta method
+    m, s = 0.005, 0.0083333
+    mu = 360 * (np.log1p(m) - 0.5 * s * s / (1 + m) ** 2)
+    sd = np.sqrt(360) * s / (1 + m)
+    lg = np.log(a.astype(np.float64) / 1000.0)
+    assert abs(lg.mean() - mu) < 5 * sd / np.sqrt(lg.size)
+    assert abs(lg.std() / sd - 1.0) < 5 / np.sqrt(2 * lg.size)
+    assert abs(a.astype(np.float64).mean() / (1000.0 * 1.005 ** 360) - 1.0) < 5 * 0.159 / np.sqrt(a.size)

@@ -46,6 +46,42 @@ def count(path, variant, kernel="paths_kernel"):
     return Counter(l.split()[0] for l in body[start:end + 1] if l.strip() and l.strip()[0] not in ';.')
 
 
+def kernel_opcodes(path, variant, kernel="paths_kernel"):
+    """Mnemonics of every instruction of smmc::(anon)::<kernel><variant>, in program order."""
+    lines = open(path).read().splitlines()
+    sym = f"_ZN4smmc12_GLOBAL__N_1{len(kernel)}{kernel}{variant}"
+    beg = [i for i, l in enumerate(lines) if l.startswith(sym)][0]
+    fin = [i for i, l in enumerate(lines) if i > beg and 's_endpgm' in l][0]
+    return [l.split()[0] for l in lines[beg + 1:fin + 1] if l.strip() and l.strip()[0] not in ';.' and not l.startswith('_Z')]
+
+
+def fingerprint(path, variant, kernel="paths_kernel"):
+    """sha256 over the kernel's instruction mnemonics in program order: changes whenever the compiled
+    kernel gains, loses or reorders an instruction (register allocation alone does not change it).
+    profiles/pmc_traffic.json stores it for the build that was profiled; tests/test_measurement_cpu.py
+    compares it with the kernels as they compile now."""
+    import hashlib
+    return hashlib.sha256("\n".join(kernel_opcodes(path, variant, kernel)).encode()).hexdigest()
+
+
+# what each workload key of profiles/pmc_traffic.json was measured on: (source file, kernel, template arguments)
+TRAFFIC_KERNELS = {"gaussian": ("smmc_kernels.hip", "paths_kernel", "ILi1ELi0ELb0E"),
+                   "table": ("smmc_kernels.hip", "paths_kernel", "ILi0ELi0ELb1E"),
+                   "ref": ("smmc_ref_kernels.hip", "ref_windowed_kernel", "ILi0E")}
+
+
+def source_digest():
+    """sha256 over the kernel sources and the compiler flags: what bench.py can check at run time (no
+    compiler needed) before it quotes a PMC figure."""
+    import hashlib
+    sys.path.insert(0, ROOT)
+    from stock_market_monte_carlo_amd import build as B
+    h = hashlib.sha256(" ".join(B.FLAGS).encode())
+    for name in ("smmc_kernels.hip", "smmc_ref_kernels.hip", "smmc_device.h", "smmc_internal.h", "smmc_bm_tables.inc"):
+        h.update(open(os.path.join(B.CSRC, name), "rb").read())
+    return h.hexdigest()
+
+
 def valu(c):
     return sum(n for k, n in c.items() if k.startswith('v_'))
 

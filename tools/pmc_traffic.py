@@ -8,6 +8,11 @@ provenance string stored beside the number.  Corrections follow MI355X_MICROARCH
 WRITE_SIZE (KiB) is exact for 16-byte-per-lane streaming stores; FETCH_SIZE (KiB) tallies 128-byte
 requests at 64 bytes on gfx950 and is doubled.
 
+Each entry also records which build it belongs to: `isa_fingerprint` (sha256 of the profiled kernel's
+instruction mnemonics, tools/isa_loop_count.py -- tests/test_measurement_cpu.py fails when the kernel as
+it compiles now differs) and `source_sha256` (kernel sources + compiler flags -- bench.py checks it at run
+time and reports `traffic: null` for a stale entry).
+
 usage: pmc_traffic.py --key "gaussian|100000000|360|all" --write DIR --fetch DIR --source TEXT
 """
 import argparse
@@ -17,6 +22,16 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_identity(mode):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import isa_loop_count as I
+    src, kernel, variant = I.TRAFFIC_KERNELS[mode]
+    asm = I.emit_asm(f"/tmp/pmc_traffic_{os.getpid()}_{src}.s", src)
+    return {"kernel": kernel + variant, "isa_fingerprint": I.fingerprint(asm, variant, kernel),
+            "source_sha256": I.source_digest()}
 
 
 def mean_counter(directory, counter, kernel="paths_kernel"):
@@ -39,14 +54,16 @@ def main():
     ap.add_argument("--source", required=True)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     a = ap.parse_args()
-    w, nw = mean_counter(a.write, "WRITE_SIZE")
-    f, nf = mean_counter(a.fetch, "FETCH_SIZE")
+    mode = a.key.split("|")[0]
+    kernel = "ref_windowed_kernel" if mode == "ref" else "paths_kernel"
+    w, nw = mean_counter(a.write, "WRITE_SIZE", kernel)
+    f, nf = mean_counter(a.fetch, "FETCH_SIZE", kernel)
     try:
         table = json.load(open(a.out))
     except (OSError, ValueError):
         table = {}
     table[a.key] = {"bytes": (w + 2.0 * f) * 1024.0, "write_size_kib": w, "fetch_size_kib": f,
-                    "dispatches": [nw, nf], "source": a.source,
+                    "dispatches": [nw, nf], "source": a.source, **build_identity(mode),
                     "correction": "WRITE_SIZE KiB x 1024 + 2 x FETCH_SIZE KiB x 1024 (gfx950 read counter tallies "
                                   "128-byte requests at 64 bytes)"}
     with open(a.out, "w") as fh:

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-3 profiling recipe (GPU box, from the repo root through gpurun).  Kernel-trace/stats and each
+# PMC group are separate rocprofv3 runs of the SAME command line bench.py is judged on: configs[1]
+# (Gaussian, the headline), configs[2] (table) and the reference CPU stream on the device (--stream ref).
+# Writes gpurun_out/$PROF_TAG/{trace_*,pmc_*}, pmc_summary.txt and pmc_traffic.json (with the ISA
+# fingerprint and source digest of the build that was profiled); copy what is judged into profiles/r03/
+# and pmc_traffic.json to profiles/.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/${PROF_TAG:-prof_r03}
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+run_passes() {  # tag, bench arguments...
+  local TAG=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$TAG -- python3 $R/bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace_$TAG.log 2>&1 || return 1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq_$TAG -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq_$TAG.log 2>&1 || return 1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_wr_$TAG -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_wr_$TAG.log 2>&1 || return 1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_rd_$TAG -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_rd_$TAG.log 2>&1 || return 1
+  echo "passes done: $TAG"
+}
+run_passes c1 --config 1 || exit 1
+run_passes c2 --config 2 || exit 1
+run_passes ref --config 2 --stream ref --outputs final || exit 1
+cd $R
+python3 tools/pmc_summary.py $OUT/pmc_sq_c1 $OUT/pmc_wr_c1 $OUT/pmc_rd_c1 $OUT/pmc_sq_c2 $OUT/pmc_wr_c2 $OUT/pmc_rd_c2 \
+        $OUT/pmc_sq_ref $OUT/pmc_wr_ref $OUT/pmc_rd_ref > $OUT/pmc_summary.txt
+SRC="profiles/r03/pmc_summary.txt (tools/profile_r03.sh)"
+python3 tools/pmc_traffic.py --key "gaussian|100000000|360|all" --write $OUT/pmc_wr_c1 --fetch $OUT/pmc_rd_c1 --source "$SRC" --out $OUT/pmc_traffic.json
+python3 tools/pmc_traffic.py --key "table|100000000|360|all" --write $OUT/pmc_wr_c2 --fetch $OUT/pmc_rd_c2 --source "$SRC" --out $OUT/pmc_traffic.json
+python3 tools/pmc_traffic.py --key "ref|100000000|360|final" --write $OUT/pmc_wr_ref --fetch $OUT/pmc_rd_ref --source "$SRC" --out $OUT/pmc_traffic.json
+for T in c1 c2 ref; do
+  F=$(find $OUT/trace_$T -name "*kernel_stats.csv" | head -1)
+  [ -n "$F" ] && cp $F $OUT/kernel_stats_$T.csv
+  tail -1 $OUT/trace_$T.log > $OUT/bench_under_rocprof_$T.json
+done
+ls $OUT
