@@ -288,6 +288,7 @@ def launch_ranks(n_ranks, argv):
     out0 = b""
     try:
         deadline = time.time() + float(os.environ.get("SMMC_BENCH_TIMEOUT", "1500"))
+        grace = float(os.environ.get("SMMC_BENCH_GRACE", "20"))  # how long the other ranks get once one has failed
         pending = set(range(n_ranks))
         failed_at = None
         while pending:
@@ -305,7 +306,7 @@ def launch_ranks(n_ranks, argv):
                 if code != 0:
                     rc = rc or code
                     failed_at = failed_at or time.time()
-            if pending and ((failed_at and time.time() - failed_at > 20.0) or time.time() > deadline):
+            if pending and ((failed_at and time.time() - failed_at > grace) or time.time() > deadline):
                 rc = rc or 124  # a rank died or the run overran: the others would wait for it forever
                 break
             time.sleep(0.05)
@@ -334,6 +335,18 @@ def launch_check(args, world, rank):
     from stock_market_monte_carlo_amd.dist import all_gather_merge_stats, shard_range
     if world > 1:
         dist.init_process_group("gloo")
+    # test hook (tests/test_bench_launch_cpu.py): rank SMMC_BENCH_TEST_DIE_RANK dies after the rendezvous and
+    # the others never come back from their step (as ranks blocked in a collective with a dead peer can):
+    # the parent must give up after its grace period, stop them and exit non-zero
+    die = os.environ.get("SMMC_BENCH_TEST_DIE_RANK")
+    if die is not None and world > 1:
+        if rank == int(die):
+            os._exit(7)
+        pid_file = os.environ.get("SMMC_BENCH_TEST_PID_FILE")
+        if pid_file:
+            with open(f"{pid_file}.{rank}", "w") as fh:
+                fh.write(str(os.getpid()))
+        time.sleep(600)
     n_total = args.total_paths or 10007 * world + 3
     first, count = shard_range(n_total, world, rank)
     n_bins = 16
@@ -388,6 +401,10 @@ def main():
                     help="with --gpus 1: still initialise the process group (one rank) and run every collective "
                          "of the N > 1 path -- barrier, the record all_gather, the max-reduce of the time -- so that "
                          "a one-GPU box exercises torch's nccl backend (RCCL)")
+    ap.add_argument("--hash-shards", type=int, default=0, metavar="K",
+                    help="outputs=host only, after the timed region: report a 64-bit digest of the final values in the "
+                         "host buffer -- N > 1: every rank's own buffer, in rank order; N = 1: of the K contiguous shares "
+                         "a K-rank run would hold -- so that a multi-rank run can be compared with a one-rank run bit for bit")
     ap.add_argument("--launch-check", action="store_true",
                     help="CPU-only rehearsal of rank launch + rendezvous + the statistics gather (no GPU work)")
     args = ap.parse_args()
@@ -512,6 +529,20 @@ def main():
     else:
         devices = [mine]
 
+    host_digests = None
+    if to_host and args.hash_shards:
+        import hashlib
+
+        def digest(a):
+            return hashlib.blake2b(np.ascontiguousarray(a).view(np.uint8), digest_size=8).hexdigest()
+
+        if world > 1:
+            host_digests = [None] * world
+            dist.all_gather_object(host_digests, digest(host_final))
+        else:
+            host_digests = [digest(host_final[f:f + c]) for f, c in (shard_range(n, args.hash_shards, i)
+                                                                      for i in range(args.hash_shards))]
+
     extra = None
     if rank == 0 and world == 1 and want_final:
         try:
@@ -596,6 +627,8 @@ def main():
         if to_host:
             out["host_pipeline"] = {"bytes_to_host_per_step": 4.0 * n, "GBps_rank0": 4.0 * n * args.steps / dt / 1e9,
                                     "kernel_busy_frac": k_s / dt if dt > 0 else None, "pinned": True}
+        if host_digests is not None:
+            out["host_digests"] = host_digests
         if stats is not None:
             out["result"] = {"mean": stats.mean, "std": stats.std, "below_initial": stats.below,
                              "hist_total": int(stats.hist.sum()) + stats.underflow + stats.overflow}

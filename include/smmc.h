@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SMMC_ABI_VERSION 2
+#define SMMC_ABI_VERSION 3
 
 /* return codes */
 #define SMMC_OK 0
@@ -134,7 +134,10 @@ void smmc_engine_destroy(smmc_engine *e);
 
 /* Re-binds the engine to another stream of its device (e.g. the caller's CURRENT torch stream,
  * passed before every call).  Work already enqueued stays ordered before anything enqueued
- * afterwards.  An engine-owned stream is drained and destroyed.  smmc_engine_get_stream returns the
+ * afterwards.  An engine-owned stream is drained and destroyed.  A caller's stream must outlive the
+ * work the engine enqueued on it; if it was destroyed after that work finished, the next set_stream
+ * still succeeds (the event record on the dead handle fails, the engine lets the device drain and
+ * adopts the new stream) -- every other call uses the stream bound last, so re-bind first.  smmc_engine_get_stream returns the
  * handle launches go to (so a caller can order its own streams against an engine-owned one). */
 int smmc_engine_set_stream(smmc_engine *e, void *stream);
 int smmc_engine_get_stream(smmc_engine *e, void **stream);
@@ -194,12 +197,16 @@ int smmc_engine_set_progress(smmc_engine *e, smmc_progress_fn fn, void *user);
  *   progress         set (atomic release store) to the number of finished paths after every
  *                    chunk (the n_simulations counter of src/simulations.cpp:254); when it or a
  *                    progress callback is given, chunks shrink to about n_paths / 16 (at least
- *                    2^20 paths) so that a poller sees the run advance
+ *                    2^16 paths) so that a poller sees the run advance
  * Environment: SMMC_PIN_HOST=whole|chunk|0: a host_final of 32 MiB or more that is not pinned
- * already is page-locked (hipHostRegister) for the duration of the call -- the whole buffer up front
- * (default: registration runs at 25-75 GB/s and lets the copies overlap the kernels), or chunk by
- * chunk one chunk ahead of the copies, or not at all; a failed registration silently falls back to
- * the pageable copy.  SMMC_HOST_CHUNK_PATHS overrides the chunk length.  Results never depend on either.
+ * already is page-locked (hipHostRegister, whole pages) for the duration of the call -- the whole
+ * buffer up front (default: registration runs at 25-75 GB/s and lets the copies overlap the kernels),
+ * or chunk by chunk one chunk ahead of the copies (every page has one owning chunk), or not at all; a
+ * failed registration falls back to the pageable copy (reported under SMMC_VERBOSE).
+ * SMMC_HOST_CHUNK_PATHS overrides the chunk length.  The per-path values, the chunk means / variances,
+ * the counters, min / max and the histogram never depend on the chunk length (and so not on whether
+ * progress is polled); sum and sumsq are double sums of the per-chunk records in chunk order and can
+ * differ in their last bits between two chunkings.
  *   stats, hist      merged statistics header and n_bins bucket counts
  * Synchronous. */
 int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *host_final,
@@ -274,6 +281,65 @@ int smmc_engine_divide_kind(smmc_engine *e, const smmc_sim *sim, int keepdata);
 
 /* Launch geometry the engine will use (workgroups x threads), for reports. */
 int smmc_engine_geometry(smmc_engine *e, uint32_t *grid, uint32_t *block, uint32_t *compute_units);
+
+/* ---- several devices of one process ----------------------------------------------------- */
+
+/* A group runs ONE simulation request sharded over several devices of this process and produces ONE
+ * merged result: the multi-GPU launcher of the reference (mc_simulations_multi_gpu_launcher_async,
+ * src/simulations.cu:576-655, reached through mc_simulations_gpu(..., n_gpus), :661-680) with the
+ * defects SURVEY section 0.7 lists removed -- shard g covers floor(N/G) paths plus one of the N mod G
+ * leftovers (the reference drops them, :602-603), global path ids are the stream counter so the
+ * result does not depend on G (the reference replays the same seeds on every GPU, :120,140), one host
+ * thread per device so that all devices compute and copy at once.
+ *
+ * How the per-device statistics records become one is chosen at creation:
+ *   SMMC_MERGE_HOST  every device's record (864 bytes at 100 buckets) is already in host memory when its
+ *                    thread returns; they are added in device order.
+ *   SMMC_MERGE_RCCL  ncclCommInitAll over the group's devices (once, kept for the group's lifetime;
+ *                    librccl.so.1 is opened only then), and per call ONE grouped all-reduce
+ *                    (ncclUint64, ncclSum) over [count, below, underflow, overflow] and the bucket
+ *                    counts, after which EVERY device holds the merged integer record in its own HBM
+ *                    (smmc_group_device_record); the two double sums and min / max are merged on
+ *                    the host in device order (an all-reduce would make them arrival-order
+ *                    dependent).  Needs distinct devices.
+ * Both give the same bits.  DESIGN.md section 7 has the measured cost of each. */
+typedef struct smmc_group smmc_group;
+#define SMMC_MERGE_HOST 0
+#define SMMC_MERGE_RCCL 1
+
+/* devices[0 .. n_devices): HIP device ids; with SMMC_MERGE_HOST a device may appear more than once
+ * (each occurrence gets its own engine and stream: several shards on one GPU). */
+int smmc_group_create(const int *devices, int n_devices, int merge, smmc_group **out);
+void smmc_group_destroy(smmc_group *g);
+int smmc_group_size(const smmc_group *g);
+
+/* smmc_engine_set_table on every device of the group. */
+int smmc_group_set_table(smmc_group *g, const float *returns_percent, uint32_t n);
+
+/* Progress of smmc_group_simulate, summed over the devices (see smmc_engine_set_progress). */
+int smmc_group_set_progress(smmc_group *g, smmc_progress_fn fn, void *user);
+
+/* smmc_engine_simulate_to_host for the whole request: device g simulates its contiguous share of the
+ * global path ids sim->first_path .. first_path + n_paths - 1 and streams it to its place in the host
+ * arrays (any may be NULL; a pageable host_final of 32 MiB or more is page-locked ONCE for all devices);
+ * stats / hist receive the merged record.  The chunk arrays need every shard to start on a multiple
+ * of SMMC_CHUNK paths: SMMC_ERR_INVALID otherwise.  Synchronous. */
+int smmc_group_simulate(smmc_group *g, const smmc_sim *sim, float *host_final, float *host_chunk_mean,
+                        float *host_chunk_var, volatile int64_t *progress, smmc_stats *stats, uint64_t *hist);
+
+/* The shard device `index` of the group gets of an n_paths request: its first path (relative to
+ * sim->first_path) and its count. */
+int smmc_group_shard(const smmc_group *g, uint64_t n_paths, int index, uint64_t *first, uint64_t *count);
+
+/* SMMC_MERGE_RCCL, after a smmc_group_simulate that asked for statistics: the device pointer (on device
+ * `index` of the group) of that device's copy of the merged packed record -- integer fields and
+ * bucket counts are the merged ones, sum / sumsq / min / max that device's own. */
+int smmc_group_device_record(smmc_group *g, int index, void **d_record);
+
+/* Host wall-clock costs in milliseconds, for reports: creating the engines, creating the communicator
+ * (opening librccl the first time included; 0 for SMMC_MERGE_HOST), and the merge step of the last
+ * smmc_group_simulate. */
+int smmc_group_timings(const smmc_group *g, double *engines_ms, double *comm_init_ms, double *last_merge_ms);
 
 /* ---- statistics record helpers (host) --------------------------------------- */
 

@@ -15,7 +15,7 @@ if os.environ.get("SMMC_LIB"):
     LIB_PATH = os.path.abspath(os.environ["SMMC_LIB"])
     print(f"stock_market_monte_carlo_amd: DEVELOPMENT library {LIB_PATH} (SMMC_LIB)", file=_sys.stderr)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MODE_TABLE = 0
 MODE_GAUSSIAN = 1
 FLAG_EXACT_DIV = 1
@@ -65,6 +65,7 @@ class Stats(C.Structure):
 
 # every symbol include/smmc.h declares: (name, restype, argtypes)
 DIV_FAST, DIV_EXACT, DIV_CHECKED = 0, 1, 2  # smmc_engine_divide_kind
+MERGE_HOST, MERGE_RCCL = 0, 1  # smmc_group_create
 
 SYMBOLS = [
     ("smmc_update_fund", C.c_float, [C.c_float, C.c_float]),
@@ -104,6 +105,16 @@ SYMBOLS = [
     ("smmc_engine_geometry", C.c_int,
      [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("smmc_engine_divide_kind", C.c_int, [C.c_void_p, C.POINTER(Sim), C.c_int]),
+    ("smmc_group_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("smmc_group_destroy", None, [C.c_void_p]),
+    ("smmc_group_size", C.c_int, [C.c_void_p]),
+    ("smmc_group_set_table", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    ("smmc_group_set_progress", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("smmc_group_simulate", C.c_int,
+     [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    ("smmc_group_shard", C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("smmc_group_device_record", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    ("smmc_group_timings", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("smmc_stats_bytes", C.c_uint64, [C.c_uint32]),
     ("smmc_stats_merge", C.c_int, [C.c_void_p, C.c_void_p]),
 ]

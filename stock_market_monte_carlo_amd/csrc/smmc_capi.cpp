@@ -308,13 +308,13 @@ int values_stats_enqueue(smmc_engine *e, const float *d_values, uint64_t n, floa
   return SMMC_OK;
 }
 
-// SMMC_FLAG_STREAM_REF: the reference's own stream (smmc_ref_kernels.hip).  Launches of at most 2^26 paths:
+// SMMC_FLAG_STREAM_REF: the reference's own stream (smmc_ref_kernels.hip).  Launches of at most 2^27 paths:
 // the windowed kernel where a path's outputs fit its window (n_periods <= 454), then a small generic
 // launch over the paths it left (a rejected generator output -- 1e-4 of the paths with the 1127-entry
 // table at 360 periods -- or a path that left the checked divide's window); the generic kernel for
 // everything when n_periods is larger.
 // Statistics and chunk outputs are second passes over the final values.  Device must be current.
-constexpr uint64_t kRefLaunchPaths = 1ull << 26;
+constexpr uint64_t kRefLaunchPaths = 1ull << 27;
 constexpr uint32_t kRefRedoGrid = 64;
 
 int enqueue_ref_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float *d_chunk_mean, float *d_chunk_var,
@@ -441,6 +441,8 @@ extern "C" {
 
 int smmc_abi_version(void) { return SMMC_ABI_VERSION; }
 const char *smmc_last_error(void) { return g_err; }
+// for the library's other translation units (smmc_group.cpp): the calling thread's error text
+int smmc_set_error_(int code, const char *message) { return fail(code, "%s", message ? message : ""); }
 
 float smmc_update_fund(float fund_value, float period_return) {
   // reference src/simulations.cpp:14-16; this TU is built with -ffp-contract=off
@@ -802,22 +804,37 @@ int smmc_engine_sync(smmc_engine *e) {
 
 namespace {
 
-// Page-locks [p, p + bytes) for the lifetime of the object unless the range already is (a
-// hipHostMalloc'd or registered buffer), so that D2H copies into it run at the pinned rate without
-// the runtime's staging.  Failure is not an error: the copy then takes the pageable path.
+bool verbose_env() {
+  const char *env = std::getenv("SMMC_VERBOSE");
+  return env && *env && *env != '0';
+}
+
+// Is the byte at p in memory the runtime already knows as page-locked (hipHostMalloc'd or registered)?
+bool is_pinned(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type != hipMemoryTypeUnregistered) return true;
+  (void)hipGetLastError();
+  return false;
+}
+
+// Page-locks whole pages [lo, hi) for the lifetime of the object, so that D2H copies into them run at the
+// pinned rate without the runtime's staging.  Failure is not an error -- the copy then takes the pageable
+// path -- but it is reported under SMMC_VERBOSE (a silently degraded pinned path).
 struct HostPin {
   void *p = nullptr;
   hipStream_t drain = nullptr;  // stream whose copies may still target the range when an error unwinds
-  bool pin(void *ptr, size_t bytes) {
+  bool pin_pages(uintptr_t lo, uintptr_t hi) {
     release();
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, ptr) == hipSuccess && attr.type != hipMemoryTypeUnregistered) return true;
-    (void)hipGetLastError();
-    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) {
-      (void)hipGetLastError();
+    if (hi <= lo) return true;
+    if (hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterDefault) != hipSuccess) {
+      if (verbose_env())
+        std::fprintf(stderr, "smmc: hipHostRegister of %zu bytes at %p failed (%s): this part is copied through the pageable path\n",
+                     static_cast<size_t>(hi - lo), reinterpret_cast<void *>(lo), hipGetErrorString(hipGetLastError()));
+      else
+        (void)hipGetLastError();
       return false;
     }
-    p = ptr;
+    p = reinterpret_cast<void *>(lo);
     return true;
   }
   void release() {
@@ -902,12 +919,33 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
   // measurements).  "whole" (default): one hipHostRegister over all of host_final before the first chunk;
   // "chunk": chunk c + 1 is registered by this host thread while chunk c computes, and chunk c is
   // released once its copy has finished.  Buffers that are pinned already are left alone.
-  HostPin pin_all, pin_chunk[2];
-  pin_all.drain = pin_chunk[0].drain = pin_chunk[1].drain = e->copy_stream;
-  const bool pin_whole = host_final && e->pin_policy == 1 && sizeof(float) * n >= e->pin_min_bytes;
-  const bool pin_chunks = host_final && e->pin_policy == 2 && sizeof(float) * n >= e->pin_min_bytes;
-  if (pin_whole) (void)pin_all.pin(host_final, sizeof(float) * n);
-  if (pin_chunks) (void)pin_chunk[0].pin(host_final, sizeof(float) * std::min<uint64_t>(chunk, n));
+  // Registration is by whole pages with ONE owner per page (chunks are multiples of 4 KiB but
+  // host_final need not be page aligned, so neighbouring chunks share a page; registering it twice fails
+  // and that chunk silently took the pageable path): the page in which chunk c begins belongs to chunk c,
+  // chunk c's registration ends where chunk c + 1's begins, the last one runs to the end of the buffer's
+  // last page.  The copy of chunk c is enqueued while chunks c - 1, c and c + 1 are registered, so every
+  // page it touches is pinned.  A copy may not span two registrations (hipMemcpyAsync: invalid argument),
+  // so a chunk's copy is cut where the next owner's pages begin: the tail piece (< 4 KiB) is its own copy.
+  HostPin pin_all, pin_chunk[3];
+  pin_all.drain = pin_chunk[0].drain = pin_chunk[1].drain = pin_chunk[2].drain = e->copy_stream;
+  const bool big_enough = host_final && sizeof(float) * n >= e->pin_min_bytes;
+  const bool already = big_enough && is_pinned(host_final) && is_pinned(host_final + (n - 1));
+  const bool pin_whole = big_enough && !already && e->pin_policy == 1;
+  const bool pin_chunks = big_enough && !already && e->pin_policy == 2 && chunk >= 2048;  // chunks span whole pages
+  const uintptr_t page = 4096;
+  auto page_floor = [&](const float *q) { return reinterpret_cast<uintptr_t>(q) & ~(page - 1); };
+  auto pin_chunk_c = [&](uint64_t c) {  // the pages chunk c owns
+    const uintptr_t lo = page_floor(host_final + c * chunk);
+    const uintptr_t hi = c + 1 < n_chunks ? page_floor(host_final + (c + 1) * chunk)
+                                          : (reinterpret_cast<uintptr_t>(host_final + n) + page - 1) & ~(page - 1);
+    (void)pin_chunk[c % 3].pin_pages(lo, hi);
+  };
+  if (pin_whole)
+    (void)pin_all.pin_pages(page_floor(host_final), (reinterpret_cast<uintptr_t>(host_final + n) + page - 1) & ~(page - 1));
+  if (pin_chunks) {
+    pin_chunk_c(0);
+    if (n_chunks > 1) pin_chunk_c(1);
+  }
 
   // Pipeline: the kernel of chunk c (engine stream) overlaps the D2H copies of chunk
   // c - 1 (copy stream).  Buffer b = c & 1 is reused once its copies have finished.
@@ -919,6 +957,13 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
     part.n_paths = std::min<uint64_t>(chunk, n - c * chunk);
     const uint64_t cs_here = (part.n_paths + smmc::kBlock - 1) / smmc::kBlock;
     if (c >= 2 && copies) SMMC_HIP(hipStreamWaitEvent(e->stream, e->ev_copy[b], 0));
+    if (pin_chunks && c >= 1) {  // keep chunks c - 1, c, c + 1 registered while the copy of chunk c is enqueued
+      if (c >= 2) {
+        SMMC_HIP(hipEventSynchronize(e->ev_copy[b]));  // chunk c - 2 is home (its copy ran beside kernel c - 1)
+        pin_chunk[(c - 2) % 3].release();
+      }
+      if (c + 1 < n_chunks) pin_chunk_c(c + 1);
+    }
     void *d_rec = want_stats ? static_cast<char *>(e->d_stage_stats) + rec * c : nullptr;
     float *d_cm = want_cs ? e->d_stage_cs[b] : nullptr;
     float *d_cv = want_cs ? e->d_stage_cs[b] + cs_per_chunk : nullptr;
@@ -927,9 +972,19 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
     if (copies) {
       SMMC_HIP(hipEventRecord(e->ev_compute[b], e->stream));
       SMMC_HIP(hipStreamWaitEvent(e->copy_stream, e->ev_compute[b], 0));
-      if (host_final)
-        SMMC_HIP(hipMemcpyAsync(host_final + c * chunk, e->d_stage[b], sizeof(float) * part.n_paths,
-                                hipMemcpyDeviceToHost, e->copy_stream));
+      if (host_final) {
+        char *dst = reinterpret_cast<char *>(host_final + c * chunk);
+        const char *src = reinterpret_cast<const char *>(e->d_stage[b]);
+        const size_t bytes = sizeof(float) * part.n_paths;
+        size_t head = bytes;
+        if (pin_chunks && c + 1 < n_chunks) {  // the last bytes lie in the page chunk c + 1 owns
+          const uintptr_t cut = page_floor(host_final + (c + 1) * chunk);
+          if (cut > reinterpret_cast<uintptr_t>(dst) && cut < reinterpret_cast<uintptr_t>(dst) + bytes)
+            head = cut - reinterpret_cast<uintptr_t>(dst);
+        }
+        SMMC_HIP(hipMemcpyAsync(dst, src, head, hipMemcpyDeviceToHost, e->copy_stream));
+        if (head < bytes) SMMC_HIP(hipMemcpyAsync(dst + head, src + head, bytes - head, hipMemcpyDeviceToHost, e->copy_stream));
+      }
       if (host_chunk_mean)
         SMMC_HIP(hipMemcpyAsync(host_chunk_mean + c * cs_per_chunk, d_cm, sizeof(float) * cs_here,
                                 hipMemcpyDeviceToHost, e->copy_stream));
@@ -937,15 +992,9 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
         SMMC_HIP(hipMemcpyAsync(host_chunk_var + c * cs_per_chunk, d_cv, sizeof(float) * cs_here,
                                 hipMemcpyDeviceToHost, e->copy_stream));
       SMMC_HIP(hipEventRecord(e->ev_copy[b], e->copy_stream));
-      if ((polled || pin_chunks) && c >= 1) {
+      if (polled && c >= 1) {
         SMMC_HIP(hipEventSynchronize(e->ev_copy[b ^ 1]));  // chunks 0 .. c - 1 are in the caller's memory
         report(c * chunk);
-      }
-      if (pin_chunks) {  // chunk c - 1 is home: release it, pin chunk c + 1 while chunk c computes
-        pin_chunk[b ^ 1].release();
-        if (c + 1 < n_chunks)
-          (void)pin_chunk[b ^ 1].pin(host_final + (c + 1) * chunk,
-                                     sizeof(float) * std::min<uint64_t>(chunk, n - (c + 1) * chunk));
       }
     } else if (polled) {
       // nothing is copied per chunk: chunks 0 .. c - 1 are finished when the kernel of c - 1 is
@@ -958,8 +1007,7 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
   }
   SMMC_HIP(hipStreamSynchronize(e->stream));
   if (copies) SMMC_HIP(hipStreamSynchronize(e->copy_stream));
-  pin_chunk[0].release();
-  pin_chunk[1].release();
+  for (HostPin &hp : pin_chunk) hp.release();
   pin_all.release();
 
   if (want_stats) {

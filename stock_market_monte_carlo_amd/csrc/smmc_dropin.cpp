@@ -43,8 +43,8 @@ void check(int rc) {
   if (rc != SMMC_OK) raise(rc);
 }
 
-// One engine per device for the process; an engine is not re-entrant, so calls on the
-// same device serialise on its mutex (calls on different devices run concurrently).
+// One engine per device for the process (single-device entry points); an engine is not re-entrant, so
+// calls on the same device serialise on its mutex (calls on different devices run concurrently).
 struct Slot {
   std::mutex busy;
   smmc_engine *engine = nullptr;
@@ -53,12 +53,32 @@ struct Slot {
   }
 };
 std::mutex g_slots_mutex;
-std::map<std::pair<int, int>, std::unique_ptr<Slot>> g_slots;  // (device, lane): lane > 0 only under SMMC_DEVICE_MAP
+std::map<int, std::unique_ptr<Slot>> g_slots;
 
-Slot &slot_for(int device, int lane = 0) {
+Slot &slot_for(int device) {
   std::lock_guard<std::mutex> lock(g_slots_mutex);
-  auto &s = g_slots[{device, lane}];
+  auto &s = g_slots[device];
   if (!s) s.reset(new Slot());
+  return *s;
+}
+
+// One group (smmc_group_*, include/smmc.h) per device list and merge back-end for the process: the
+// n_gpus-way entry points.  Its engines -- and, with SMMC_GROUP_MERGE=rccl, its RCCL communicator --
+// are created once and kept.
+struct GroupSlot {
+  std::mutex busy;
+  smmc_group *group = nullptr;
+  ~GroupSlot() {
+    if (group) smmc_group_destroy(group);
+  }
+};
+std::mutex g_groups_mutex;
+std::map<std::pair<std::vector<int>, int>, std::unique_ptr<GroupSlot>> g_groups;
+
+GroupSlot &group_slot_for(const std::vector<int> &devices, int merge) {
+  std::lock_guard<std::mutex> lock(g_groups_mutex);
+  auto &s = g_groups[{devices, merge}];
+  if (!s) s.reset(new GroupSlot());
   return *s;
 }
 
@@ -129,54 +149,44 @@ std::vector<int> device_map(int n_gpus) {
   return map;
 }
 
-struct Shard {
-  int index;   // 0 .. n_gpus - 1: results merge in this order
-  int device;  // where it runs
-  int lane;    // how many earlier shards share that device (0 without SMMC_DEVICE_MAP): picks the engine
-  std::uint64_t first, count;
+// The group an n_gpus-way call runs on, locked for the call, with `table` loaded (table may be null for
+// Gaussian runs).  Shard g covers floor(N/G) paths plus one of the N mod G leftovers (the reference
+// drops the remainder, src/simulations.cu:602-603); it runs on device g, or device map[g] under
+// SMMC_DEVICE_MAP.  The per-device statistics records are merged on the host in shard order, or --
+// SMMC_GROUP_MERGE=rccl, distinct devices -- by one RCCL all-reduce (both give the same bits).
+struct GroupSession {
+  std::unique_lock<std::mutex> lock;
+  smmc_group *group = nullptr;
+  GroupSession(int n_gpus, const std::vector<float> *table) {
+    if (n_gpus < 1) throw std::invalid_argument("smmc: n_gpus must be >= 1");
+    const int have = visible_devices();
+    if (have == 0) throw std::runtime_error("smmc: no MI355X visible; this library has no CPU fallback");
+    const std::vector<int> map = device_map(n_gpus);
+    bool distinct = true;
+    for (size_t a = 0; a < map.size(); ++a) {
+      if (map[a] >= have) throw std::invalid_argument("smmc: n_gpus exceeds the visible devices");
+      for (size_t b = a + 1; b < map.size(); ++b) distinct = distinct && map[a] != map[b];
+    }
+    int merge = SMMC_MERGE_HOST;
+    if (const char *env = std::getenv("SMMC_GROUP_MERGE"))
+      if (!std::strcmp(env, "rccl") && distinct) merge = SMMC_MERGE_RCCL;
+    GroupSlot &slot = group_slot_for(map, merge);
+    lock = std::unique_lock<std::mutex>(slot.busy);
+    if (!slot.group) check(smmc_group_create(map.data(), n_gpus, merge, &slot.group));
+    group = slot.group;
+    if (table) {
+      if (table->empty()) throw std::invalid_argument("smmc: empty returns table");
+      check(smmc_group_set_table(group, table->data(), static_cast<uint32_t>(table->size())));
+    }
+  }
 };
 
-// Runs `work(shard)` for each of n_gpus contiguous shards, one host thread per shard.  Shard g covers floor(N/G) paths plus one of the N mod G leftovers
-// (the reference drops the remainder, src/simulations.cu:602-603).
-template <typename Work>
-void for_each_shard(long n_total, int n_gpus, Work work) {
-  if (n_gpus < 1) throw std::invalid_argument("smmc: n_gpus must be >= 1");
-  const int have = visible_devices();
-  if (have == 0) throw std::runtime_error("smmc: no MI355X visible; this library has no CPU fallback");
-  const std::vector<int> map = device_map(n_gpus);
-  for (int d : map)
-    if (d >= have) throw std::invalid_argument("smmc: n_gpus exceeds the visible devices");
-  const std::uint64_t n = static_cast<std::uint64_t>(n_total);
-  const std::uint64_t base = n / n_gpus, extra = n % n_gpus;
-  std::vector<std::thread> threads;
-  std::vector<std::string> errors(n_gpus);
-  std::uint64_t first = 0;
-  for (int g = 0; g < n_gpus; ++g) {
-    const std::uint64_t count = base + (static_cast<std::uint64_t>(g) < extra ? 1 : 0);
-    int lane = 0;
-    for (int h = 0; h < g; ++h) lane += map[h] == map[g];
-    const Shard shard{g, map[g], lane, first, count};
-    auto body = [&, g, shard]() {
-      try {
-        work(shard);
-      } catch (const std::exception &ex) {
-        errors[g] = ex.what();
-      }
-    };
-    if (n_gpus == 1) body(); else threads.emplace_back(body);
-    first += count;
-  }
-  for (auto &t : threads) t.join();
-  for (const auto &e : errors)
-    if (!e.empty()) throw std::runtime_error(e);
-}
-
-// Engine of `device` with `table` loaded (table may be null for Gaussian runs).
+// Engine of `device` with `table` loaded (table may be null): the single-device entry points.
 struct Session {
   std::unique_lock<std::mutex> lock;
   smmc_engine *engine;
-  Session(int device, const std::vector<float> *table, int lane = 0) : lock(slot_for(device, lane).busy) {
-    Slot &s = slot_for(device, lane);
+  Session(int device, const std::vector<float> *table) : lock(slot_for(device).busy) {
+    Slot &s = slot_for(device);
     if (!s.engine) check(smmc_engine_create(device, SMMC_STREAM_NEW, &s.engine));
     engine = s.engine;
     if (table) {
@@ -186,17 +196,15 @@ struct Session {
   }
 };
 
-// Progress of a run that may be split over several shards: every engine reports its own finished-path
-// count through smmc_engine_set_progress; the deltas are added to the caller's atomic counter.
+// Progress of a run: the group reports the number of finished paths over all its devices
+// (smmc_group_set_progress); it goes to the caller's atomic counter (src/simulations.cpp:254).
 struct Progress {
   std::atomic<long> *counter;
-  long reported = 0;
   static void on_progress(void *user, int64_t finished) {
     Progress *p = static_cast<Progress *>(user);
+    long cur = p->counter->load(std::memory_order_relaxed);
     const long now = static_cast<long>(finished);
-    if (now > p->reported) {
-      p->counter->fetch_add(now - p->reported, std::memory_order_release);
-      p->reported = now;
+    while (now > cur && !p->counter->compare_exchange_weak(cur, now, std::memory_order_release)) {
     }
   }
 };
@@ -213,27 +221,15 @@ void run_final_values(std::atomic<long> &n_simulations, long n_total, unsigned p
                       const std::vector<float> *table, float mean, float stddev, float *out, int n_gpus) {
   const std::uint64_t seed = next_seed();
   n_simulations = 0;
-  const auto t_all = std::chrono::steady_clock::now();
-  for_each_shard(n_total, n_gpus, [&](const Shard &sh) {
-    const std::uint64_t first = sh.first, count = sh.count;
-    const int shard = sh.index, dev = sh.device;
-    const auto t0 = std::chrono::steady_clock::now();
-    Session ses(dev, table, sh.lane);
-    const double t_session = seconds_since(t0);
-    smmc_sim sim = make_sim(mode, seed, first, count, periods, capital);
-    sim.gauss_mean = mean;
-    sim.gauss_std = stddev;
-    Progress prog{&n_simulations};
-    check(smmc_engine_set_progress(ses.engine, &Progress::on_progress, &prog));
-    const int rc = smmc_engine_simulate_to_host(ses.engine, &sim, out + first, nullptr, nullptr, nullptr, nullptr, nullptr);
-    (void)smmc_engine_set_progress(ses.engine, nullptr, nullptr);
-    check(rc);
-    if (verbose())  // phase timers, as the reference's launchers print them (src/simulations.cu:351-358,608-610)
-      std::fprintf(stderr, "smmc: shard %d on device %d: paths [%llu, %llu): engine+table %.3f s, simulate+copy %.3f s\n",
-                   shard, dev, (unsigned long long)first, (unsigned long long)(first + count), t_session,
-                   seconds_since(t0) - t_session);
-  });
-  if (verbose()) std::fprintf(stderr, "smmc: %ld paths x %u periods on %d shard(s): %.3f s\n", n_total, periods, n_gpus, seconds_since(t_all));
+  GroupSession gs(n_gpus, table);
+  smmc_sim sim = make_sim(mode, seed, 0, static_cast<std::uint64_t>(n_total), periods, capital);
+  sim.gauss_mean = mean;
+  sim.gauss_std = stddev;
+  Progress prog{&n_simulations};
+  check(smmc_group_set_progress(gs.group, &Progress::on_progress, &prog));
+  const int rc = smmc_group_simulate(gs.group, &sim, out, nullptr, nullptr, nullptr, nullptr, nullptr);
+  (void)smmc_group_set_progress(gs.group, nullptr, nullptr);
+  check(rc);
   n_simulations = n_total;  // src/simulations.cu:678
 }
 
@@ -263,9 +259,7 @@ void resize_prefaulted_impl(std::vector<float> &v, size_t n) {
 
 // Creates (and caches) the engine of every shard of an n_gpus-way call with `table` loaded, so that
 // the HIP runtime start-up and the first allocations overlap the sizing of the result vector.
-void warm_engines(long n_total, int n_gpus, const std::vector<float> *table) {
-  for_each_shard(n_total, n_gpus, [&](const Shard &sh) { Session ses(sh.device, table, sh.lane); });
-}
+void warm_engines(long, int n_gpus, const std::vector<float> *table) { GroupSession gs(n_gpus, table); }
 
 // The callee-sized result of mc_simulations_gpu (src/simulations.cu:643-644): engines first (in a fresh
 // process that is the HIP runtime's start-up, 190-240 ms, tools/ubench_startup.cpp), then the vector
@@ -521,12 +515,10 @@ Summary mc_summary(long max_n_simulations, int n_periods, float initial_capital,
   if (max_n_simulations < 0 || n_periods < 0) throw std::invalid_argument("smmc: negative size");
   const std::uint64_t seed = next_seed();
   const size_t rec = static_cast<size_t>(smmc_stats_bytes(n_bins));
-  std::vector<std::vector<char>> records(n_gpus > 0 ? n_gpus : 1, std::vector<char>(rec));
-  for_each_shard(max_n_simulations, n_gpus, [&](const Shard &sh) {
-    const std::uint64_t first = sh.first, count = sh.count;
-    const int shard = sh.index;
-    Session ses(sh.device, gaussian ? nullptr : &returns, sh.lane);
-    smmc_sim sim = make_sim(gaussian ? SMMC_MODE_GAUSSIAN : SMMC_MODE_TABLE, seed, first, count,
+  std::vector<char> record(rec);
+  {
+    GroupSession gs(n_gpus, gaussian ? nullptr : &returns);
+    smmc_sim sim = make_sim(gaussian ? SMMC_MODE_GAUSSIAN : SMMC_MODE_TABLE, seed, 0, static_cast<std::uint64_t>(max_n_simulations),
                             static_cast<unsigned>(n_periods), initial_capital);
     sim.gauss_mean = return_mean;
     sim.gauss_std = return_std;
@@ -534,13 +526,10 @@ Summary mc_summary(long max_n_simulations, int n_periods, float initial_capital,
     sim.n_bins = n_bins;
     sim.hist_lo = hist_lo;
     sim.hist_hi = hist_hi;
-    smmc_stats *hdr = reinterpret_cast<smmc_stats *>(records[shard].data());
-    check(smmc_engine_simulate_to_host(ses.engine, &sim, nullptr, nullptr, nullptr, nullptr, hdr,
-                                       reinterpret_cast<uint64_t *>(records[shard].data() + sizeof(smmc_stats))));
-    hdr->n_bins = n_bins;
-  });
-  for (int g = 1; g < n_gpus; ++g) check(smmc_stats_merge(records[0].data(), records[g].data()));  // shard order
-  const smmc_stats *h = reinterpret_cast<const smmc_stats *>(records[0].data());
+    check(smmc_group_simulate(gs.group, &sim, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<smmc_stats *>(record.data()),
+                              reinterpret_cast<uint64_t *>(record.data() + sizeof(smmc_stats))));
+  }
+  const smmc_stats *h = reinterpret_cast<const smmc_stats *>(record.data());
   Summary out;
   out.count = h->count;
   out.below = h->below;

@@ -131,6 +131,7 @@ class Engine:
     # -- configuration -------------------------------------------------------
     def set_table(self, returns_percent):
         t = np.ascontiguousarray(returns_percent, dtype=np.float32)
+        self._enter()  # never act on a stream bound by an earlier call: the caller may have destroyed it since
         _lib.check(self._L.smmc_engine_set_table(self._h, t.ctypes.data_as(C.c_void_p), t.size))
         self.table_len = int(t.size)
 
@@ -145,6 +146,7 @@ class Engine:
     def kernel_ms(self):
         """(summed main-kernel milliseconds, launches) since the last call; synchronises."""
         ms, n = C.c_double(), C.c_uint32()
+        self._enter()
         _lib.check(self._L.smmc_engine_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
@@ -155,6 +157,10 @@ class Engine:
         return a.value
 
     def sync(self):
+        """Waits for everything the engine has enqueued.  A "torch" engine first re-binds to the caller's
+        current stream (work enqueued on the stream of an earlier call stays ordered before it; a stream
+        handed to the engine must outlive its pending work, not the engine)."""
+        self._enter()
         _lib.check(self._L.smmc_engine_sync(self._h))
 
     # -- simulation ----------------------------------------------------------
@@ -311,6 +317,80 @@ class Engine:
         _lib.check(self._L.smmc_engine_simulate_keepdata_to_host(
             self._h, C.byref(sim), traj.ctypes.data_as(C.c_void_p), final.ctypes.data_as(C.c_void_p)))
         return traj, final
+
+
+class Group:
+    """Several devices of this process behind one call (smmc_group_*, include/smmc.h): the request is
+    sharded by contiguous global path ids, every device streams its share to its place in the host
+    arrays, and ONE merged statistics record comes back -- merged on the host in device order
+    (merge="host") or by one RCCL all-reduce of the integer fields (merge="rccl", distinct devices).
+    Reference: mc_simulations_multi_gpu_launcher_async, src/simulations.cu:576-655."""
+
+    def __init__(self, devices, merge="host"):
+        self._L = _lib.lib()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        kind = {"host": _lib.MERGE_HOST, "rccl": _lib.MERGE_RCCL}[merge]
+        _lib.check(self._L.smmc_group_create(devs, len(devices), kind, C.byref(h)))
+        self._h = h
+        self.merge = merge
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.smmc_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._L.smmc_group_size(self._h))
+
+    def set_table(self, returns_percent):
+        t = np.ascontiguousarray(returns_percent, dtype=np.float32)
+        _lib.check(self._L.smmc_group_set_table(self._h, t.ctypes.data_as(C.c_void_p), t.size))
+
+    def shard(self, n_paths, index):
+        first, count = C.c_uint64(), C.c_uint64()
+        _lib.check(self._L.smmc_group_shard(self._h, n_paths, index, C.byref(first), C.byref(count)))
+        return first.value, count.value
+
+    def simulate(self, sim, out=None, want_final=True, want_stats=False, want_chunk_stats=False, progress=None):
+        """Returns (final or None, Stats or None, (chunk means, chunk variances))."""
+        n = int(sim.n_paths)
+        host = None
+        if want_final:
+            host = out if out is not None else np.empty(n, dtype=np.float32)
+            assert host.dtype == np.float32 and host.size >= n and host.flags.c_contiguous
+        st = _lib.Stats()
+        hist = np.zeros(max(int(sim.n_bins), 1), dtype=np.uint64)
+        nc = (n + _lib.CHUNK - 1) // _lib.CHUNK
+        cm = np.empty(nc, dtype=np.float32) if want_chunk_stats else None
+        cv = np.empty(nc, dtype=np.float32) if want_chunk_stats else None
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+        _lib.check(self._L.smmc_group_simulate(
+            self._h, C.byref(sim), vp(host), vp(cm), vp(cv), C.byref(progress) if progress is not None else None,
+            C.byref(st) if want_stats else None, vp(hist) if want_stats else None))
+        stats = None
+        if want_stats:
+            stats = Stats(st.count, st.below, st.underflow, st.overflow, st.sum, st.sumsq, st.min, st.max,
+                          hist[: int(sim.n_bins)])
+        return host, stats, (cm, cv)
+
+    def device_record(self, index):
+        """merge="rccl": device pointer (int) of device `index`'s copy of the merged packed record."""
+        p = C.c_void_p()
+        _lib.check(self._L.smmc_group_device_record(self._h, index, C.byref(p)))
+        return int(p.value or 0)
+
+    def timings(self):
+        """(engines up, communicator init, merge step of the last simulate) in milliseconds."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self._L.smmc_group_timings(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
 
 # ---------------------------------------------------------------------------

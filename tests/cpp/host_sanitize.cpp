@@ -111,6 +111,20 @@ static void no_device_paths() {
   EXPECT(smmc_engine_set_stream(nullptr, nullptr) == SMMC_ERR_INVALID);
   EXPECT(smmc_engine_set_progress(nullptr, nullptr, nullptr) == SMMC_ERR_INVALID);
   EXPECT(smmc_engine_quartiles(nullptr, nullptr, 0, nullptr) == SMMC_ERR_INVALID);
+  // the group entry: argument checks, and no device -> no group
+  smmc_group *grp = reinterpret_cast<smmc_group *>(1);
+  const int devs[3] = {0, 0, 1};
+  EXPECT(smmc_group_create(nullptr, 1, SMMC_MERGE_HOST, &grp) == SMMC_ERR_INVALID && grp == nullptr);
+  EXPECT(smmc_group_create(devs, 0, SMMC_MERGE_HOST, &grp) == SMMC_ERR_INVALID);
+  EXPECT(smmc_group_create(devs, 1, 7, &grp) == SMMC_ERR_INVALID);
+  EXPECT(smmc_group_create(devs, 2, SMMC_MERGE_RCCL, &grp) == SMMC_ERR_INVALID);  // device 0 twice
+  EXPECT(smmc_group_create(devs, 1, SMMC_MERGE_HOST, nullptr) == SMMC_ERR_INVALID);
+  if (n == 0) EXPECT(smmc_group_create(devs, 3, SMMC_MERGE_HOST, &grp) == SMMC_ERR_NO_DEVICE && grp == nullptr);
+  smmc_group_destroy(nullptr);
+  EXPECT(smmc_group_size(nullptr) == 0);
+  EXPECT(smmc_group_simulate(nullptr, &sim, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == SMMC_ERR_INVALID);
+  EXPECT(smmc_group_set_table(nullptr, nullptr, 0) == SMMC_ERR_INVALID);
+  EXPECT(smmc_group_timings(nullptr, nullptr, nullptr, nullptr) == SMMC_ERR_INVALID);
   if (n != 0) return;  // the rest is the loud failure of every engine entry without a GPU
   std::vector<float> table = smmc::bundled_synthetic_returns(), out(10, 0.f), means, vars;
   std::vector<std::vector<float>> data(10);

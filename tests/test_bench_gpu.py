@@ -63,3 +63,40 @@ def test_two_self_launched_ranks_share_the_gpu_and_merge_to_the_single_rank_resu
     assert two["result"]["below_initial"] == one["result"]["below_initial"]
     assert two["result"]["mean"] == pytest.approx(one["result"]["mean"], rel=1e-12)
     assert two["result"]["std"] == pytest.approx(one["result"]["std"], rel=1e-10)
+
+
+def test_two_ranks_config1_weak_scaling_conserves_counts_and_equals_one_rank_over_the_same_ids():
+    """BASELINE configs[1] shape with two self-launched ranks (weak scaling: every rank its own
+    paths-per-gpu, rank r the ids [r n, (r + 1) n)): rank count, total paths, count conservation, and the
+    merged record equal to ONE rank simulating the ids [0, 2 n)."""
+    n = 3_000_000
+    two = _run("--gpus", "2", "--backend", "gloo", "--config", "1", "--paths-per-gpu", str(n), "--steps", "2", "--warmup", "1",
+               timeout=600)
+    one = _run("--config", "1", "--paths-per-gpu", str(2 * n), "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["backend"] == "gloo" and two["launcher"] == "self"
+    assert two["scaling"] == "weak" and two["config"]["paths_rank0"] == n and two["config"]["paths_all_ranks"] == 2 * n
+    assert two["config"]["outputs"] == "all" and two["config"]["mode"] == "gaussian" and two["config"]["n_periods"] == 360
+    assert two["result"]["hist_total"] == 2 * n == one["result"]["hist_total"]
+    assert two["result"]["below_initial"] == one["result"]["below_initial"]
+    assert two["result"]["mean"] == pytest.approx(one["result"]["mean"], rel=1e-12)
+    assert two["result"]["std"] == pytest.approx(one["result"]["std"], rel=1e-10)
+    assert two["value"] == pytest.approx(2 * n * 2 / (two["ms_per_step"] * 2e-3), rel=1e-6)  # whole-job paths / max-over-ranks time
+
+
+def test_two_ranks_config4_host_buffers_equal_the_halves_of_the_one_rank_run():
+    """BASELINE configs[4] shape (P = 1000, final values to pinned host memory through the side-stream
+    pipeline, no collective) with two self-launched ranks: each rank's host buffer is, bit for bit, its
+    half of what one rank computes for the whole id range (digests of the buffers; the remainder of the odd
+    total goes to rank 0)."""
+    total = 2_000_001
+    two = _run("--gpus", "2", "--backend", "gloo", "--config", "4", "--total-paths", str(total), "--steps", "2", "--warmup", "1",
+               "--hash-shards", "2", timeout=600)
+    one = _run("--config", "4", "--total-paths", str(total), "--steps", "2", "--warmup", "1", "--hash-shards", "2",
+               "--no-cpu-baseline")
+    assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["paths_all_ranks"] == total and two["config"]["paths_rank0"] == 1_000_001
+    assert two["config"]["outputs"] == "host" and two["config"]["n_periods"] == 1000
+    assert "no collective" in two["config"]["parallelism"]
+    assert len(two["host_digests"]) == 2 and two["host_digests"] == one["host_digests"]
+    assert two["host_digests"][0] != two["host_digests"][1]
+    assert two["host_pipeline"]["bytes_to_host_per_step"] == 4.0 * 1_000_001

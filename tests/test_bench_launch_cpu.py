@@ -76,3 +76,29 @@ def test_presets_name_the_baseline_configs():
     assert bench.CONFIGS[4]["outputs"] == "host"
     for k, c in bench.CONFIGS.items():
         assert f"configs[{k}]" in c["name"]
+
+
+def test_a_rank_that_dies_mid_run_ends_the_run_within_the_grace_period(tmp_path):
+    """One rank exits after the rendezvous, the other never returns from its step (a rank blocked in a
+    collective with a dead peer): the parent waits its grace period (20 s by default, 3 s here), stops
+    exactly the ranks it started, and exits with the dead rank's code -- bench.py's `failed_at` branch."""
+    import time
+    pid_file = str(tmp_path / "rank_pid")
+    env = dict(_env(), SMMC_BENCH_TEST_DIE_RANK="1", SMMC_BENCH_TEST_PID_FILE=pid_file, SMMC_BENCH_GRACE="3")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--launch-check"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    took = time.time() - t0
+    assert r.returncode == 7, (r.returncode, r.stderr[-1000:])
+    assert not _json_lines(r.stdout)
+    assert took < 120  # start-up of two ranks + 3 s grace + the stop; never the 600 s the survivor would sleep
+    survivor = int(open(pid_file + ".0").read())
+    time.sleep(0.5)
+    alive = True
+    try:
+        os.kill(survivor, 0)
+    except ProcessLookupError:
+        alive = False
+    except PermissionError:
+        pass
+    assert not alive, "the surviving rank was left behind"

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(L):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(L, name), name
-    assert L.smmc_abi_version() == _lib.ABI_VERSION == 2
+    assert L.smmc_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_struct_layout_matches_header(L):

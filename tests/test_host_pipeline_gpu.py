@@ -89,14 +89,16 @@ def test_pinning_policies_do_not_change_results(table, oracle, monkeypatch, poli
     eng.close()
 
 
-def test_progress_advances_in_steps(table):
-    """With a progress pointer the chunks shrink to ~N/16 (>= 2^20 paths): a poller sees the counter move."""
+@pytest.mark.parametrize("n,periods", [(20_000_000, 8), (1_000_000, 360)])
+def test_progress_advances_in_steps(table, n, periods):
+    """With a progress pointer the chunks shrink to ~N/16 (>= 2^16 paths): a poller sees the counter move
+    -- also at BASELINE configs[0] size (1e6 paths x 360 periods), where round 2's 2^20-path floor made
+    the counter jump 0 -> N (the reference adds 1000 paths at a time, src/simulations.cpp:254)."""
     import threading
     import stock_market_monte_carlo_amd as S
     eng = S.Engine(0)
     eng.set_table(table)
-    n = 20_000_000
-    sim = S.Engine.make_sim(n, 8, S.MODE_TABLE, 5)
+    sim = S.Engine.make_sim(n, periods, S.MODE_TABLE, 5)
     prog = C.c_int64(0)
     seen, stop = set(), threading.Event()
 
@@ -111,7 +113,49 @@ def test_progress_advances_in_steps(table):
     t.join()
     assert prog.value == n
     mid = sorted(v for v in seen if 0 < v < n)
-    assert len(mid) >= 3 and all(v % 256 == 0 for v in mid)
+    assert len(mid) >= 3 and all(v % 1024 == 0 for v in mid)
+    eng.close()
+
+
+def test_polled_and_unpolled_runs_agree_except_in_the_last_bits_of_the_sums(table):
+    """polling shortens the chunks, and the statistics record is merged over chunks.  What the
+    header promises: final values, counters, min / max and histogram do not depend on it; sum and sumsq are
+    double sums in chunk order -- equal to 1e-13, not necessarily bit for bit."""
+    import stock_market_monte_carlo_amd as S
+    eng = S.Engine(0)
+    eng.set_table(table)
+    n = 40_000_000 + 321
+    sim = S.Engine.make_sim(n, 8, S.MODE_TABLE, 9, n_bins=64, hist_lo=500.0, hist_hi=2000.0)
+    plain, st_plain, _ = eng.simulate_to_host(sim, want_stats=True)
+    prog = C.c_int64(0)
+    polled, st_polled, _ = eng.simulate_to_host(sim, want_stats=True, progress=prog)
+    assert prog.value == n and np.array_equal(plain.view(np.uint32), polled.view(np.uint32))
+    assert (st_plain.count, st_plain.below, st_plain.underflow, st_plain.overflow, st_plain.min, st_plain.max) == \
+           (st_polled.count, st_polled.below, st_polled.underflow, st_polled.overflow, st_polled.min, st_polled.max)
+    assert np.array_equal(st_plain.hist, st_polled.hist)
+    assert st_polled.sum == pytest.approx(st_plain.sum, rel=1e-13) and st_polled.sumsq == pytest.approx(st_plain.sumsq, rel=1e-13)
+    eng.close()
+
+
+def test_chunk_pinning_on_a_buffer_that_is_not_page_aligned(table, oracle, monkeypatch, capfd):
+    """SMMC_PIN_HOST=chunk on a result buffer that starts in the middle of a page: neighbouring chunks share
+    pages, every page has one owning chunk, and no registration falls back (SMMC_VERBOSE would say so)."""
+    import stock_market_monte_carlo_amd as S
+    eng = _fresh_engine(table, monkeypatch, SMMC_PIN_HOST="chunk", SMMC_HOST_CHUNK_PATHS=1 << 21, SMMC_VERBOSE=1)
+    n, p = 5 * (1 << 21) + 777, 4  # 40 MiB + a tail: six chunks
+    backing = np.full(n + 4096, -1.0, dtype=np.float32)
+    off = (-(backing.ctypes.data // 4) % 1024 + 100) % 1024 + 1  # 4-byte aligned, never on a page boundary
+    out = backing[off:off + n]
+    assert out.ctypes.data % 4096 != 0
+    sim = S.Engine.make_sim(n, p, S.MODE_TABLE, 11)
+    host, _, _ = eng.simulate_to_host(sim, out=out)
+    dev = eng.simulate(sim).final.cpu().numpy()
+    assert np.array_equal(host.view(np.uint32), dev.view(np.uint32))
+    assert backing[off - 1] == -1.0 and backing[off + n] == -1.0
+    assert "hipHostRegister" not in capfd.readouterr().err
+    host2, _, _ = eng.simulate_to_host(sim, out=out)  # every page was released: registers again
+    assert np.array_equal(host2.view(np.uint32), dev.view(np.uint32))
+    assert "hipHostRegister" not in capfd.readouterr().err
     eng.close()
 
 
@@ -151,4 +195,45 @@ def test_engine_owned_stream_is_ordered_with_torch(table, oracle):
         r = eng.simulate(sim)
         got = r.final.clone()  # torch's stream waits for the engine's
         assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    eng.close()
+
+
+def test_a_stream_destroyed_while_torch_still_holds_the_outputs(table, oracle):
+    """Round 2's segfault: the engine's own stream was wrapped for torch's caching allocator,
+    which then polled events on a stream the engine had destroyed.  Now ordering is by events at call time
+    only -- destroy the engine (and its stream) while the output tensors are still alive and unread, then
+    use, free and re-allocate them."""
+    import gc
+    import torch
+    import stock_market_monte_carlo_amd as S
+    want = oracle.counter_mc(oracle.make_params(oracle.MODE_TABLE, 36, 50_000, 77, table=table))["final"]
+    sim = S.Engine.make_sim(50_000, 36, S.MODE_TABLE, 77, n_bins=10, hist_lo=0.0, hist_hi=5000.0)
+    held = []
+    for _ in range(3):
+        eng = S.Engine(0, stream="new")
+        eng.set_table(table)
+        r = eng.simulate(sim, want_stats=True, want_chunk_stats=True)
+        eng.close()  # drains and destroys the engine-owned stream; r's tensors are still held, not yet read
+        held.append(r)
+    for r in held:
+        assert np.array_equal(r.final.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    del held, r
+    gc.collect()
+    torch.cuda.empty_cache()  # the allocator frees the blocks: nothing refers to the dead streams
+    x = torch.empty(1 << 22, device="cuda").normal_()
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all()
+    # a caller's stream that dies between two calls of a "torch" engine: the next call re-binds and runs
+    eng = S.Engine(0)
+    eng.set_table(table)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        r = eng.simulate(sim)
+    side.synchronize()
+    del side
+    gc.collect()
+    r2 = eng.simulate(sim)
+    eng.sync()
+    assert np.array_equal(r2.final.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(r.final.cpu().numpy().view(np.uint32), want.view(np.uint32))
     eng.close()

@@ -32,6 +32,6 @@ python3 tools/pmc_traffic.py --key "ref|100000000|360|final" --write $OUT/pmc_wr
 for T in c1 c2 ref; do
   F=$(find $OUT/trace_$T -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && cp $F $OUT/kernel_stats_$T.csv
-  tail -1 $OUT/trace_$T.log > $OUT/bench_under_rocprof_$T.json
+  grep '^{"metric"' $OUT/trace_$T.log | tail -1 > $OUT/bench_under_rocprof_$T.json
 done
 ls $OUT
