@@ -562,7 +562,7 @@ def main():
         value = n_all * args.steps / dt
         k_s = kernel_ms / 1e3  # summed kernel time of this rank's launches in the timed region
         k_avg_s = k_s / max(launches, 1)
-        paths_per_launch = n * args.steps / max(launches, 1)  # host pipeline: one launch per 2^24-path chunk
+        paths_per_launch = n * args.steps / max(launches, 1)  # host pipeline: one launch per 2^22-path chunk
         writes_final = want_final or to_host
         bytes_per_launch = 4.0 * paths_per_launch if writes_final else 0.0
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0

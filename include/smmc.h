@@ -52,6 +52,7 @@ extern "C" {
  * smmc_engine_simulate_to_host); statistics and chunk outputs are formed from the final values by a
  * second pass.  About 3.5x the arithmetic of the default stream (624 words of generator state per path). */
 #define SMMC_FLAG_STREAM_REF 4u
+#define SMMC_FLAG_QUIET 8u /* no SMMC_VERBOSE phase lines for this request (the drop-in's warm-up run) */
 
 /* paths per chunk of the per-chunk mean/variance outputs: the reference's
  * THREADS_PER_BLOCK (src/simulations.cu:17), one (mean, variance) pair per block
@@ -186,7 +187,7 @@ int smmc_engine_sync(smmc_engine *e);
 typedef void (*smmc_progress_fn)(void *user, int64_t finished_paths);
 int smmc_engine_set_progress(smmc_engine *e, smmc_progress_fn fn, void *user);
 
-/* Simulates into HOST memory: outputs are produced in chunks of 2^24 paths and
+/* Simulates into HOST memory: outputs are produced in chunks of 2^22 paths and
  * copied back on a side stream while the next chunk computes (the async
  * cudaMemcpy pattern of mc_simulations_multi_gpu_launcher_async,
  * src/simulations.cu:615-626, without its extra host copy :643-644).
@@ -212,6 +213,18 @@ int smmc_engine_set_progress(smmc_engine *e, smmc_progress_fn fn, void *user);
 int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *host_final,
                                  float *host_chunk_mean, float *host_chunk_var, volatile int64_t *progress,
                                  smmc_stats *stats, uint64_t *hist);
+
+/* Optional: allocates now what the next smmc_engine_simulate_to_host of up to n_paths final values will
+ * need on the device (its two staging buffers), so that the first call of a process does not pay for it
+ * -- e.g. while another host thread sizes the result buffer.  Results never depend on it. */
+int smmc_engine_prepare_host(smmc_engine *e, uint64_t n_paths);
+
+/* Page-locks / releases a caller's host buffer (hipHostRegister over its whole pages, visible to every
+ * device): a buffer registered here is used as it is by smmc_engine_simulate_to_host and
+ * smmc_group_simulate (no registration per call; 12-15 ms per 400 MB the first time).  A buffer that is
+ * pinned already is left alone (SMMC_OK; smmc_host_unregister of it is then a no-op). */
+int smmc_host_register(void *host_ptr, uint64_t bytes);
+int smmc_host_unregister(void *host_ptr);
 
 /* keepdata into HOST memory: host_traj is n_paths x (n_periods + 1) floats path-major,
  * host_final (may be NULL) n_paths floats.  Produced in device-sized slices.
@@ -326,6 +339,9 @@ int smmc_group_set_progress(smmc_group *g, smmc_progress_fn fn, void *user);
  * of SMMC_CHUNK paths: SMMC_ERR_INVALID otherwise.  Synchronous. */
 int smmc_group_simulate(smmc_group *g, const smmc_sim *sim, float *host_final, float *host_chunk_mean,
                         float *host_chunk_var, volatile int64_t *progress, smmc_stats *stats, uint64_t *hist);
+
+/* smmc_engine_prepare_host on every device of the group, for its share of n_paths (in parallel). */
+int smmc_group_prepare_host(smmc_group *g, uint64_t n_paths);
 
 /* The shard device `index` of the group gets of an n_paths request: its first path (relative to
  * sim->first_path) and its count. */

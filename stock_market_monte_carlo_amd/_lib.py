@@ -20,6 +20,7 @@ MODE_TABLE = 0
 MODE_GAUSSIAN = 1
 FLAG_EXACT_DIV = 1
 FLAG_STREAM_V2 = 2  # counter stream v2 (round 1's) instead of v3
+FLAG_QUIET = 8
 FLAG_STREAM_REF = 4  # the reference CPU engine's own stream: per-path mt19937 + libstdc++ Lemire map (table mode)
 CHUNK = 256
 MAX_TABLE = 16384
@@ -87,6 +88,10 @@ SYMBOLS = [
     ("smmc_engine_sync", C.c_int, [C.c_void_p]),
     ("smmc_engine_simulate_to_host", C.c_int,
      [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    ("smmc_engine_prepare_host", C.c_int, [C.c_void_p, C.c_uint64]),
+    ("smmc_host_register", C.c_int, [C.c_void_p, C.c_uint64]),
+    ("smmc_host_unregister", C.c_int, [C.c_void_p]),
+    ("smmc_group_prepare_host", C.c_int, [C.c_void_p, C.c_uint64]),
     ("smmc_engine_simulate_keepdata_to_host", C.c_int, [C.c_void_p, C.POINTER(Sim), C.c_void_p, C.c_void_p]),
     ("smmc_engine_values_stats", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),

@@ -257,21 +257,58 @@ void resize_prefaulted_impl(std::vector<float> &v, size_t n) {
   v.resize(n);
 }
 
-// Creates (and caches) the engine of every shard of an n_gpus-way call with `table` loaded, so that
-// the HIP runtime start-up and the first allocations overlap the sizing of the result vector.
-void warm_engines(long, int n_gpus, const std::vector<float> *table) { GroupSession gs(n_gpus, table); }
+// The callee-sized result of mc_simulations_gpu (src/simulations.cu:643-644), made ready beside the
+// engines.  In a fresh process the group's engines cost the HIP runtime's start-up (190-290 ms) plus
+// 25-40 ms of their own; sizing the 400 MB vector costs 17-20 ms and page-locking it 12-15 ms.  The
+// engines (and the staging buffers of the host pipeline) come up on a helper thread while this thread
+// sizes the vector and registers it, so that the first smmc_group_simulate finds everything in place
+// (profiles/r03/cold_start.txt has the phases).  The registration is released by PinnedResult.
+struct PinnedResult {
+  void *ptr = nullptr;
+  void pin(std::vector<float> &v) {
+    const char *policy = std::getenv("SMMC_PIN_HOST");
+    const bool never = policy && std::strcmp(policy, "1") && std::strcmp(policy, "whole") && std::strcmp(policy, "chunk");
+    if (never || v.size() * sizeof(float) < (size_t(32) << 20)) return;
+    if (smmc_host_register(v.data(), v.size() * sizeof(float)) == SMMC_OK) ptr = v.data();  // failure: pageable copies
+  }
+  ~PinnedResult() {
+    if (ptr) (void)smmc_host_unregister(ptr);
+  }
+};
 
-// The callee-sized result of mc_simulations_gpu (src/simulations.cu:643-644): engines first (in a fresh
-// process that is the HIP runtime's start-up, 190-240 ms, tools/ubench_startup.cpp), then the vector
-// (17-20 ms).  Sizing it on a helper thread beside the start-up was tried and saved nothing measurable.
-void size_result_and_warm(std::vector<float> &totals, long n_total, int n_gpus, const std::vector<float> *table) {
+void size_result_and_warm(std::vector<float> &totals, long n_total, int n_gpus, const std::vector<float> *table,
+                          PinnedResult &pinned, int mode, unsigned periods, float capital) {
   const auto t0 = std::chrono::steady_clock::now();
-  warm_engines(n_total, n_gpus, table);
-  const double t_warm = seconds_since(t0);
+  std::exception_ptr warm_error;
+  double t_warm = 0.0;
+  std::thread warm([&] {
+    try {
+      GroupSession gs(n_gpus, table);
+      check(smmc_group_prepare_host(gs.group, static_cast<std::uint64_t>(n_total)));
+      // a throw-away run of a few paths through the same kernel variant and the same pipeline: the
+      // first launch and the first device-to-host copy of a process cost ~7 ms that the real run
+      // would otherwise pay (its values go nowhere; the seed is the caller's business, not this one's)
+      const std::uint64_t n_warm = static_cast<std::uint64_t>(std::min<long>(n_total, 256L * n_gpus));
+      if (n_warm) {
+        std::vector<float> scratch(n_warm);
+        smmc_sim sim = make_sim(mode, 1, 0, n_warm, periods, capital);
+        sim.flags |= SMMC_FLAG_QUIET;
+        check(smmc_group_simulate(gs.group, &sim, scratch.data(), nullptr, nullptr, nullptr, nullptr, nullptr));
+      }
+    } catch (...) {
+      warm_error = std::current_exception();
+    }
+    t_warm = seconds_since(t0);
+  });
   resize_prefaulted_impl(totals, static_cast<size_t>(n_total));
+  const double t_sized = seconds_since(t0);
+  pinned.pin(totals);
+  const double t_pinned = seconds_since(t0);
+  warm.join();
+  if (warm_error) std::rethrow_exception(warm_error);
   if (verbose())
-    std::fprintf(stderr, "smmc: engines up in %.3f s, result vector (%ld floats) sized in %.3f s\n", t_warm, n_total,
-                 seconds_since(t0) - t_warm);
+    std::fprintf(stderr, "smmc: engines up in %.3f s; beside them: result vector (%ld floats) sized in %.3f s, page-locked in %.3f s\n",
+                 t_warm, n_total, t_sized, t_pinned - t_sized);
 }
 
 }  // namespace
@@ -396,7 +433,8 @@ void mc_simulations_gpu(std::atomic<long> &n_simulations, long max_n_simulations
                         float initial_capital, std::vector<float> &returns, std::vector<float> &totals,
                         int n_gpus) {
   if (max_n_simulations < 0 || n_periods < 0) throw std::invalid_argument("smmc: negative size");
-  size_result_and_warm(totals, max_n_simulations, n_gpus, &returns);  // callee-owned result, src/simulations.cu:643-644
+  PinnedResult pinned;
+  size_result_and_warm(totals, max_n_simulations, n_gpus, &returns, pinned, SMMC_MODE_TABLE, static_cast<unsigned>(n_periods), initial_capital);  // callee-owned result, src/simulations.cu:643-644
   run_final_values(n_simulations, max_n_simulations, static_cast<unsigned>(n_periods), initial_capital,
                    SMMC_MODE_TABLE, &returns, 0.f, 0.f, totals.data(), n_gpus);
 }
@@ -498,7 +536,8 @@ void mc_simulations_gpu_gaussian(std::atomic<long> &n_simulations, long max_n_si
                                  float initial_capital, float return_mean, float return_std,
                                  std::vector<float> &totals, int n_gpus) {
   if (max_n_simulations < 0 || n_periods < 0) throw std::invalid_argument("smmc: negative size");
-  size_result_and_warm(totals, max_n_simulations, n_gpus, nullptr);
+  PinnedResult pinned;
+  size_result_and_warm(totals, max_n_simulations, n_gpus, nullptr, pinned, SMMC_MODE_GAUSSIAN, static_cast<unsigned>(n_periods), initial_capital);
   run_final_values(n_simulations, max_n_simulations, static_cast<unsigned>(n_periods), initial_capital,
                    SMMC_MODE_GAUSSIAN, nullptr, return_mean, return_std, totals.data(), n_gpus);
 }

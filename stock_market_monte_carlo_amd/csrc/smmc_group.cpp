@@ -258,6 +258,29 @@ int smmc_group_set_progress(smmc_group *g, smmc_progress_fn fn, void *user) {
   return SMMC_OK;
 }
 
+int smmc_group_prepare_host(smmc_group *g, uint64_t n_paths) {
+  if (!g) return fail(SMMC_ERR_INVALID, "group is NULL");
+  const int G = static_cast<int>(g->devices.size());
+  std::vector<int> rcs(G, SMMC_OK);
+  std::vector<std::string> errs(G);
+  auto run = [&](int i) {
+    uint64_t first, count;
+    shard_of(n_paths, G, i, &first, &count);
+    rcs[i] = smmc_engine_prepare_host(g->engines[i], count);
+    if (rcs[i] != SMMC_OK) errs[i] = smmc_last_error();
+  };
+  if (G == 1) {
+    run(0);
+  } else {
+    std::vector<std::thread> threads;
+    for (int i = 0; i < G; ++i) threads.emplace_back(run, i);
+    for (auto &t : threads) t.join();
+  }
+  for (int i = 0; i < G; ++i)
+    if (rcs[i] != SMMC_OK) return fail(rcs[i], "device %d: %s", g->devices[i], errs[i].c_str());
+  return SMMC_OK;
+}
+
 int smmc_group_shard(const smmc_group *g, uint64_t n_paths, int index, uint64_t *first, uint64_t *count) {
   if (!g || !first || !count) return fail(SMMC_ERR_INVALID, "NULL argument");
   if (index < 0 || index >= static_cast<int>(g->devices.size())) return fail(SMMC_ERR_INVALID, "no device %d in the group", index);
@@ -357,7 +380,7 @@ int smmc_group_simulate(smmc_group *g, const smmc_sim *sim, float *host_final, f
     if (polled) (void)smmc_engine_set_progress(e, nullptr, nullptr);
     if (rcs[i] != SMMC_OK) errs[i] = smmc_last_error();
     hdr->n_bins = sim->n_bins;
-    if (verbose_env())  // phase timers, as the reference's launchers print them (src/simulations.cu:351-358,608-610)
+    if (verbose_env() && !(sim->flags & SMMC_FLAG_QUIET))  // phase timers, as the reference's launchers print them (src/simulations.cu:351-358,608-610)
       std::fprintf(stderr, "smmc: shard %d on device %d: paths [%llu, %llu): simulate+copy %.3f s\n", i, g->devices[i],
                    static_cast<unsigned long long>(first), static_cast<unsigned long long>(first + count), ms_since(t0) / 1e3);
   };
@@ -371,7 +394,7 @@ int smmc_group_simulate(smmc_group *g, const smmc_sim *sim, float *host_final, f
   if (pinned) (void)hipHostUnregister(pinned);
   for (int i = 0; i < G; ++i)
     if (rcs[i] != SMMC_OK) return fail(rcs[i], "shard %d on device %d: %s", i, g->devices[i], errs[i].c_str());
-  if (verbose_env())
+  if (verbose_env() && !(sim->flags & SMMC_FLAG_QUIET))
     std::fprintf(stderr, "smmc: %llu paths x %u periods on %d shard(s): %.3f s\n", static_cast<unsigned long long>(n),
                  sim->n_periods, G, ms_since(t_all) / 1e3);
 

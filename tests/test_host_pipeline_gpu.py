@@ -50,8 +50,8 @@ def test_config4_path_many_host_chunks_against_the_oracle(table, oracle, monkeyp
 
 
 def test_config4_full_chunk_size_spot_check(table, oracle):
-    """The real chunk length (2^24 paths) at P = 1000: two chunks + a tail into pinned memory; the
-    first, the chunk-boundary and the last paths against the oracle, the rest by count conservation."""
+    """The real chunk length (2^22 paths) at P = 1000: eight chunks + a tail into pinned memory; the
+    first, chunk-boundary and last paths against the oracle, the rest by count conservation."""
     import torch
     import stock_market_monte_carlo_amd as S
     eng = S.Engine(0)
@@ -60,7 +60,7 @@ def test_config4_full_chunk_size_spot_check(table, oracle):
     pinned = torch.empty(n, dtype=torch.float32, pin_memory=True).numpy()
     host, st, _ = eng.simulate_to_host(sim, out=pinned, want_stats=True)
     assert st.count == n and int(st.hist.sum()) + st.underflow + st.overflow == n
-    for first in (0, (1 << 24) - 100, (1 << 25) - 100, n - 200):
+    for first in (0, (1 << 22) - 100, (1 << 24) - 100, (1 << 25) - 100, n - 200):
         o = oracle.counter_mc(oracle.make_params(oracle.MODE_GAUSSIAN, p, 200, SEED, first_path=first))
         assert np.array_equal(host[first:first + 200].view(np.uint32), o["final"].view(np.uint32)), first
     assert float(host.astype(np.float64).sum()) == pytest.approx(st.sum, rel=1e-12)
