@@ -29,13 +29,15 @@
  *       follows src/simulations.cpp:204-266 with deterministic per-path seeds
  *       (the reference seeds from std::random_device and has no seed argument).
  *       This is what bench.py times as the CPU baseline ("port").
- *   (C) "counter stream v3" (default; v2's Gaussian draw with orc_params.stream = 2):
- *       Philox4x32-10 keyed by the 64-bit seed, counter =
- *       (global path id, step block, stream tag); table-indexed (eight draws per
- *       block for tables <= 2048 entries) or Box-Muller Gaussian draws; the same
- *       three-rounding compounding step.  The HIP
- *       kernels must reproduce this engine bit-for-bit (final values, histogram
- *       bucket counts, below-threshold counts).
+ *   (C) "counter stream v3" (default) and v2 (orc_params.stream = 2): Philox4x32-10 keyed by
+ *       the 64-bit seed.  The stream number selects the COUNTER LAYOUT IN BOTH MODES --
+ *       v3: (step block, path id lo, path id hi, mode tag); v2: (path id lo, path id hi,
+ *       step block, mode tag) -- and the Gaussian draw (v3's cheaper Box-Muller, or
+ *       v2's).  So table-mode results for a given seed differ between the streams too:
+ *       round 1's table-mode values are reproduced only with stream = 2.  Table-indexed
+ *       draws (eight per block for tables <= 2048 entries) or Box-Muller Gaussian draws;
+ *       the same three-rounding compounding step.  The HIP kernels must reproduce this
+ *       engine bit-for-bit (final values, histogram bucket counts, below-threshold counts).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
  * -ffp-contract=off matters: every fused multiply-add below is an explicit
@@ -255,7 +257,8 @@ ORC_API void orc_box_muller(uint32_t ua, uint32_t ub, float *z_cos, float *z_sin
 
 /* ---- counter stream v3: the same construction with cheaper arithmetic ---------------------------
  * (round 2: the Gaussian path step is bound by VALU instruction count; v2 needs 30.5 per period on
- * the device, v3 18.  Table mode is the same in v2 and v3.)
+ * the device, v3 17.5.  The table DRAW -- index digits, table entry, step -- is the same in v2 and v3;
+ * the Philox counter layout is not (path_returns_block), so table-mode VALUES differ between them.)
  * Radius: the first word read as int32 is the SIGNED distance d of the uniform from the nearer end of
  * (0, 1) in units of 2^-32 (d > 0: from 0; d < 0: from 1); f = (float)d (round to nearest even,
  * |f| <= 2^31), u = |f| / 2^32 in (0, 1/2]; d = 0 stands for u = 2^-33.  Exponent 127 .. 158: 32 octaves x
@@ -335,7 +338,8 @@ typedef struct {
   uint32_t n_bins;       /* 0 = no histogram */
   float hist_lo, hist_hi;
   float below_threshold;
-  uint32_t stream;       /* Gaussian draw: 2 = counter stream v2, anything else (0, 3) = v3 */
+  uint32_t stream;       /* 2 = counter stream v2, anything else (0, 3) = v3: the Philox counter layout in BOTH modes
+                          * (path_returns_block) and the Gaussian draw */
 } orc_params;
 
 typedef struct {

@@ -6,8 +6,11 @@
                           This pins the oracle's hand-written mt19937 / Lemire map.
   counter_stream_v2.json  frozen outputs of the oracle's counter-stream engine (C):
   counter_stream_v3.json  regression vectors for the HIP kernels that also travel to
-                          the GPU box (v2: round 1's Gaussian draw, selected with
-                          SMMC_FLAG_STREAM_V2; v3: the default).  Pinned to the oracle itself only.
+                          the GPU box (v2: round 1's stream, selected with SMMC_FLAG_STREAM_V2;
+                          v3: the default).  The stream number sets the Philox counter layout in
+                          BOTH modes, so the table-mode values of counter_stream_v3.json are NOT
+                          those of round 1 (counter_stream_v2.json holds them, bit-unchanged).
+                          Pinned to the oracle itself only.
 
 The reference implementation could not be built here (see oracle/Makefile), so no
 fixture in this directory comes from an executed reference.
