@@ -48,9 +48,10 @@ extern "C" {
  * std::mt19937 seeded with (uint32_t)(seed + id) -- the reference seeds each path from a fresh
  * std::random_device and has no seed argument -- through libstdc++'s uniform_int_distribution<int>
  * (Lemire's map with rejection), then update_fund.  With the seeds the reference's generators got, the
- * final values are the reference's, bit for bit.  Final-value launches only (smmc_engine_simulate,
- * smmc_engine_simulate_to_host); statistics and chunk outputs are formed from the final values by a
- * second pass.  About 3.5x the arithmetic of the default stream (624 words of generator state per path). */
+ * final values (and, with the keepdata entries, the trajectories: mc_simulations_keepdata draws the same
+ * way, src/simulations.cpp:175-186) are the reference's, bit for bit.  Statistics and chunk outputs are
+ * formed from the final values by a second pass.  About 3.5x the arithmetic of the default stream (624
+ * words of generator state per path). */
 #define SMMC_FLAG_STREAM_REF 4u
 #define SMMC_FLAG_QUIET 8u /* no SMMC_VERBOSE phase lines for this request (the drop-in's warm-up run) */
 

@@ -342,7 +342,7 @@ constexpr uint64_t kRefLaunchPaths = 1ull << 27;
 constexpr uint32_t kRefRedoGrid = 64;
 
 int enqueue_ref_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float *d_chunk_mean, float *d_chunk_var,
-                           void *d_stats) {
+                           void *d_stats, float *d_traj = nullptr) {
   const uint64_t n = s->n_paths;
   float *fin = d_final;
   if (!fin && n) {
@@ -379,8 +379,9 @@ int enqueue_ref_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, fl
       SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_ref_ws), smmc::ref_workspace_bytes(ws_grid)));
       e->ref_ws_grid = ws_grid;
     }
-    if (static_cast<size_t>(T) * sizeof(float) + 2048 > e->max_lds)
-      return fail(SMMC_ERR_INVALID, "the table needs %zu bytes of LDS, device allows %zu", static_cast<size_t>(T) * 4, e->max_lds);
+    if (smmc::ref_windowed_lds_bytes(T, d_traj != nullptr) + 2048 > e->max_lds)
+      return fail(SMMC_ERR_INVALID, "the table needs %zu bytes of LDS, device allows %zu",
+                  smmc::ref_windowed_lds_bytes(T, d_traj != nullptr), e->max_lds);
     smmc::RefArgs a;
     std::memset(&a, 0, sizeof a);
     a.table_a = e->d_table;
@@ -397,6 +398,7 @@ int enqueue_ref_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, fl
       a.seed0 = static_cast<uint32_t>(s->seed + s->first_path + first);
       a.n_paths = static_cast<uint32_t>(count);
       a.d_final = fin + first;
+      a.d_traj = d_traj ? d_traj + first * (static_cast<uint64_t>(P) + 1) : nullptr;
       const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((count + smmc::kBlock - 1) / smmc::kBlock, e->max_grid));
       if (windowed) {
         a.redo_count = e->d_ref_redo;
@@ -707,10 +709,11 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   if ((reinterpret_cast<uintptr_t>(d_traj) | reinterpret_cast<uintptr_t>(d_final)) & 3u)
     return fail(SMMC_ERR_INVALID, "d_traj and d_final must be 4-byte aligned");
   if (sim->n_periods >= (1u << 24)) return fail(SMMC_ERR_INVALID, "keepdata supports n_periods < 2^24");
-  if (sim->flags & SMMC_FLAG_STREAM_REF) return fail(SMMC_ERR_INVALID, "SMMC_FLAG_STREAM_REF: final-value launches only");
   DeviceGuard guard(e->device);
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
   if (sim->n_paths == 0) return SMMC_OK;
+  if (sim->flags & SMMC_FLAG_STREAM_REF)  // the reference's own stream: its kernels keep the trajectories themselves
+    return enqueue_ref_simulation(e, sim, d_final, nullptr, nullptr, nullptr, d_traj);
   float unused_lo, unused_hi;
   const bool exact_div = divide_kind(e, sim, false, &unused_lo, &unused_hi) != SMMC_DIV_FAST;
 

@@ -422,7 +422,6 @@ void mc_simulations_keepdata(std::atomic<long> &n_simulations, long max_n_simula
   for (size_t first = 0; first < n; first += slice) {
     const size_t count = std::min(slice, n - first);
     smmc_sim sim = make_sim(SMMC_MODE_TABLE, seed, first, count, n_periods, initial_capital);
-    sim.flags &= ~SMMC_FLAG_STREAM_REF;  // trajectories come from the counter stream only (include/smmc.h)
     check(smmc_engine_simulate_keepdata_to_host(ses.engine, &sim, flat.data(), final_values.data() + first));
     for (size_t i = 0; i < count; ++i) mc_data[first + i].assign(flat.begin() + i * row, flat.begin() + (i + 1) * row);
     n_simulations += static_cast<long>(count);  // src/simulations.cpp:190

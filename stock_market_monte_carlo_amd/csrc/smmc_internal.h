@@ -54,12 +54,14 @@ struct RefArgs {
   float initial_capital;
   float chk_lo, chk_hi;   // SMMC_DIV_CHECKED: as KernelArgs
   float *d_final;         // n_paths floats
+  float *d_traj;          // nullable: n_paths rows of n_periods + 1 floats (keepdata)
   uint32_t *redo_count;   // windowed kernel: paths it left unfinished (appended to redo_list); generic kernel
   uint32_t *redo_list;    //   with redo_list != nullptr: the work items are redo_list[0 .. *redo_count)
   uint32_t *workspace;    // generic kernel: ref_workspace_bytes(grid)
 };
 uint32_t ref_windowed_max_outputs();
 size_t ref_workspace_bytes(uint32_t grid);
+size_t ref_windowed_lds_bytes(uint32_t table_len, bool traj);
 hipError_t launch_ref_windowed(const RefArgs &a, int div, uint32_t grid, hipStream_t stream);
 hipError_t launch_ref_generic(const RefArgs &a, bool exact_div, uint32_t grid, hipStream_t stream);
 hipError_t launch_chunk_stats(const float *values, uint64_t n, float *d_mean, float *d_var, uint32_t grid,

@@ -73,13 +73,14 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // Lemire map picks the table entry or rejects the output; an accepted one is a period
 // (src/simulations.cpp:250).
 template <bool kExactDiv>
-__device__ __forceinline__ void offer(const RefArgs &k, const float *lds_table, uint32_t g, float &total, uint32_t &need) {
+__device__ __forceinline__ bool offer(const RefArgs &k, const float *lds_table, uint32_t g, float &total, uint32_t &need) {
   const uint32_t y = mt_temper(g);
   const uint64_t prod = static_cast<uint64_t>(y) * k.table_len;
   const bool take = static_cast<uint32_t>(prod) >= k.reject_below && need != 0u;
   const float next = compound<kExactDiv>(total, lds_table[static_cast<uint32_t>(prod >> 32)]);
   total = take ? next : total;
   need -= take ? 1u : 0u;
+  return take;
 }
 
 // The seed words a path's next output needs, as chains advanced in step with the output index j.
@@ -130,11 +131,37 @@ __device__ __forceinline__ uint32_t window_next_b(MtWindow &w, uint32_t j, uint3
 // would come from the next output: its lane is flagged instead (one v_cmp whose result is OR-ed into a
 // scalar mask) and the path is left to the generic kernel -- 1e-4 of the paths for the 1127-entry table
 // at 360 periods.  That keeps the loop free of per-lane state: no accept/select, no draw counter.
-template <int kDiv>
+//
+// kTraj (mc_simulations_keepdata, src/simulations.cpp:139-202: the same generator per path, every value
+// kept): lanes own paths, so one period's values are a column of the path-major output.  A wave parks
+// 32 periods x 64 paths in its own LDS tile ([64][33] words: the column writes and the row reads are both
+// conflict-free) and writes the tile out a row at a time -- 32 lanes one row's 128 contiguous bytes, two
+// rows per store instruction -- instead of 64 four-byte stores into 64 different lines per period.
+constexpr uint32_t kTrajTileCols = 32, kTrajTileStride = kTrajTileCols + 1;
+constexpr uint32_t kTrajTileWords = 64 * kTrajTileStride;  // per wave
+
+// Writes columns [0, count) of the wave's tile: value `first_k + c` of the rows row0 .. row0 + 63.
+__device__ __forceinline__ void traj_tile_flush(const RefArgs &k, const float *tile, uint32_t row0, uint32_t first_k, uint32_t count) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t lane = threadIdx.x & 63u, col = lane & 31u, half = lane >> 5;
+#pragma unroll 4
+  for (uint32_t rr = 0; rr < 32u; ++rr) {
+    const uint32_t r = 2u * rr + half;
+    const uint32_t row = row0 + r;
+    if (col < count && row < k.n_paths)
+      k.d_traj[static_cast<size_t>(row) * (k.n_periods + 1u) + first_k + col] = tile[r * kTrajTileStride + col];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int kDiv, bool kTraj>
 __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
   extern __shared__ __align__(16) float lds_table[];
   for (uint32_t i = threadIdx.x; i < k.table_len; i += kBlock) lds_table[i] = k.table_a[i];
   __syncthreads();
+  float *const tile = lds_table + ((k.table_len + 3u) & ~3u) + (threadIdx.x >> 6) * kTrajTileWords;  // kTraj only
   constexpr bool kExactDiv = kDiv == kDivExact;
   const uint32_t P = k.n_periods;  // <= ref_windowed_max_outputs()
   const uint32_t n_chunks = (k.n_paths + kBlock - 1u) / kBlock;  // n_paths <= 2^31
@@ -158,7 +185,14 @@ __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
       if constexpr (kDiv == kDivChecked) {  // the window of divide_kind() (smmc_capi.cpp): at least every 8 periods
         if ((j & 7u) == 7u) redo_mask |= __ballot(!(total > k.chk_lo && total < k.chk_hi));
       }
+      if constexpr (kTraj) {  // value j + 1 of the row goes to column j mod 32 of the tile
+        tile[(threadIdx.x & 63u) * kTrajTileStride + (j & 31u)] = total;
+        if ((j & 31u) == 31u) traj_tile_flush(k, tile, chunk * kBlock + (threadIdx.x & ~63u), j - 30u, 32u);
+      }
     };
+    if constexpr (kTraj) {
+      if (i < k.n_paths) k.d_traj[static_cast<size_t>(i) * (P + 1u)] = total;  // values[0]: the initial capital
+    }
     // four outputs per trip, written out (a loop holding a ballot is not unrolled with a remainder)
     uint32_t j = 0;
     const uint32_t first = P < kMtLag ? P : kMtLag;
@@ -180,6 +214,9 @@ __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
       }
       for (; j < P; ++j) period(window_next_b(w, j, j - kMtLag + 2u, j + kMtM - kMtLag + 1u), j);
     }
+    if constexpr (kTraj) {
+      if (P & 31u) traj_tile_flush(k, tile, chunk * kBlock + (threadIdx.x & ~63u), (P & ~31u) + 1u, P & 31u);
+    }
     if (i < k.n_paths) {
       if ((redo_mask >> (threadIdx.x & 63u)) & 1u) {
         k.redo_list[atomicAdd(k.redo_count, 1u)] = i;  // finished by ref_generic_kernel with the IEEE divide
@@ -193,7 +230,9 @@ __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
 // Any number of periods: the circular state in global memory, word s of lane l at workspace[s * L + l]
 // (L = lanes of the launch).  Work items are the paths 0 .. n_paths - 1, or -- redo_list given -- the
 // *redo_count paths the windowed kernel left over.
-template <bool kExactDiv>
+// kTraj: a lane that rejected outputs is at a period of its own, so every lane stores its own value (one
+// 4-byte store per lane and period into its own row: the slow store shape, kept to the fallback).
+template <bool kExactDiv, bool kTraj>
 __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
   extern __shared__ __align__(16) float lds_table[];
   for (uint32_t i = threadIdx.x; i < k.table_len; i += kBlock) lds_table[i] = k.table_a[i];
@@ -217,6 +256,11 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
     }
     float total = k.initial_capital;
     uint32_t need = active ? P : 0u;
+    float *row = nullptr;
+    if constexpr (kTraj) {
+      row = k.d_traj + static_cast<size_t>(i) * (P + 1u);
+      if (active) row[0] = total;
+    }
     uint32_t xnh = seed >> 1;  // x[j] >> 1
     uint32_t s = 0;      // j mod 624; batches of 8 never straddle the wrap (624 = 8 x 78)
     auto wrap = [](uint32_t v) { return v >= kMtN ? v - kMtN : v; };
@@ -232,7 +276,10 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
         const uint32_t n1h = n1[t] >> 1;
         const uint32_t g = m[t] ^ mt_twist_term(xnh, n1h, n1[t]);
         W[static_cast<size_t>(s + t) * L] = g;  // x[j + t + 624] takes the place of x[j + t]
-        offer<kExactDiv>(k, lds_table, g, total, need);
+        const bool took = offer<kExactDiv>(k, lds_table, g, total, need);
+        if constexpr (kTraj) {
+          if (took) row[P - need] = total;
+        }
         xnh = n1h;
       }
       s = wrap(s + 8u);
@@ -280,36 +327,47 @@ __global__ __launch_bounds__(kBlock) void chunk_stats_kernel(const float *values
 uint32_t ref_windowed_max_outputs() { return kMtN - 170u; }  // 454: outputs the windowed kernel can generate
 size_t ref_workspace_bytes(uint32_t grid) { return static_cast<size_t>(grid) * kBlock * kMtN * sizeof(uint32_t); }
 
+size_t ref_windowed_lds_bytes(uint32_t table_len, bool traj) {
+  return (static_cast<size_t>((table_len + 3u) & ~3u) + (traj ? kWaves * kTrajTileWords : 0u)) * sizeof(float);
+}
+
+namespace {
+template <typename Kernel>
+hipError_t launch_ref(Kernel kernel, const RefArgs &a, uint32_t grid, size_t lds, hipStream_t stream) {
+  if (lds > 60u * 1024u) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds));
+    if (err != hipSuccess) return err;
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, a);
+  return hipGetLastError();
+}
+}  // namespace
+
+// a.d_traj != nullptr: every value of every path as well (rows of n_periods + 1 floats)
 hipError_t launch_ref_windowed(const RefArgs &a, int div, uint32_t grid, hipStream_t stream) {
-  const size_t lds = static_cast<size_t>(a.table_len) * sizeof(float);
-  auto go = [&](auto kernel) {
-    if (lds > 60u * 1024u) {
-      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(lds));
-      if (err != hipSuccess) return err;
-    }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, a);
-    return hipGetLastError();
-  };
+  const bool traj = a.d_traj != nullptr;
+  const size_t lds = ref_windowed_lds_bytes(a.table_len, traj);
   switch (div) {
-    case SMMC_DIV_FAST: return go(ref_windowed_kernel<kDivFast>);
-    case SMMC_DIV_CHECKED: return go(ref_windowed_kernel<kDivChecked>);
-    default: return go(ref_windowed_kernel<kDivExact>);
+    case SMMC_DIV_FAST:
+      return traj ? launch_ref(ref_windowed_kernel<kDivFast, true>, a, grid, lds, stream)
+                  : launch_ref(ref_windowed_kernel<kDivFast, false>, a, grid, lds, stream);
+    case SMMC_DIV_CHECKED:
+      return traj ? launch_ref(ref_windowed_kernel<kDivChecked, true>, a, grid, lds, stream)
+                  : launch_ref(ref_windowed_kernel<kDivChecked, false>, a, grid, lds, stream);
+    default:
+      return traj ? launch_ref(ref_windowed_kernel<kDivExact, true>, a, grid, lds, stream)
+                  : launch_ref(ref_windowed_kernel<kDivExact, false>, a, grid, lds, stream);
   }
 }
 
 hipError_t launch_ref_generic(const RefArgs &a, bool exact_div, uint32_t grid, hipStream_t stream) {
   const size_t lds = static_cast<size_t>(a.table_len) * sizeof(float);
-  auto go = [&](auto kernel) {
-    if (lds > 60u * 1024u) {
-      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(lds));
-      if (err != hipSuccess) return err;
-    }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, a);
-    return hipGetLastError();
-  };
-  return exact_div ? go(ref_generic_kernel<true>) : go(ref_generic_kernel<false>);
+  if (a.d_traj)
+    return exact_div ? launch_ref(ref_generic_kernel<true, true>, a, grid, lds, stream)
+                     : launch_ref(ref_generic_kernel<false, true>, a, grid, lds, stream);
+  return exact_div ? launch_ref(ref_generic_kernel<true, false>, a, grid, lds, stream)
+                   : launch_ref(ref_generic_kernel<false, false>, a, grid, lds, stream);
 }
 
 hipError_t launch_chunk_stats(const float *values, uint64_t n, float *d_mean, float *d_var, uint32_t grid, hipStream_t stream) {

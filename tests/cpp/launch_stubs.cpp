@@ -24,6 +24,7 @@ size_t keepdata_lds_bytes(uint32_t, int, int, int) { return 0; }
 hipError_t static_lds_bytes(size_t *bytes) { *bytes = 0; return hipSuccess; }
 uint32_t ref_windowed_max_outputs() { return 454; }
 size_t ref_workspace_bytes(uint32_t grid) { return static_cast<size_t>(grid) * 256 * 624 * 4; }
+size_t ref_windowed_lds_bytes(uint32_t table_len, bool) { return static_cast<size_t>(table_len) * 4; }
 hipError_t launch_ref_windowed(const RefArgs &, int, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_ref_generic(const RefArgs &, bool, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_chunk_stats(const float *, uint64_t, float *, float *, uint32_t, hipStream_t) { return hipErrorNoDevice; }

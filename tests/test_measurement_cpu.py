@@ -44,7 +44,7 @@ def test_ref_stream_instruction_counts_match_the_built_kernel(tmp_path):
     import isa_loops as L
     asm = I.emit_asm(str(tmp_path / "smmc_ref_kernels.s"), "smmc_ref_kernels.hip")
     lines = open(asm).read().splitlines()
-    body = L.kernel_body(lines, "ref_windowed_kernelILi0E")
+    body = L.kernel_body(lines, "ref_windowed_kernelILi0ELb0E")
     found = sorted((L.summary(c)[0], c) for _, c in L.loops(body))
     (hi, c_hi), (lo, c_lo) = found[-1], found[-2]
     assert hi == pytest.approx(bench.REF_VALU["output_hi"] * 4) and lo == pytest.approx(bench.REF_VALU["output_lo"] * 4)

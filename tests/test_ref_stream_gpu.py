@@ -174,9 +174,53 @@ def test_argument_errors(eng):
     sim = Engine.make_sim(10, 4, MODE_GAUSSIAN, 1, stream="ref")
     with pytest.raises(SmmcError, match="table mode only"):
         eng.simulate(sim)
-    with pytest.raises(SmmcError, match="final-value launches only"):
-        eng.simulate_keepdata(_sim(10, 4, 1))
     # empty launch: a zero record, nothing written
     r = eng.simulate(_sim(0, 360, 1, n_bins=10, hist_lo=0.0, hist_hi=1.0), want_final=True, want_stats=True)
     st = eng.read_stats(r.stats_raw)
     assert st.count == 0 and int(st.hist.sum()) == 0
+
+
+@pytest.mark.parametrize("p", [0, 1, 31, 32, 33, 64, 227, 360, 454, 455, 700])
+def test_trajectories_of_the_reference_stream(eng, oracle, table, p):
+    """mc_simulations_keepdata draws like mc_simulations (src/simulations.cpp:175-186: a generator per path,
+    sample_returns_historical, many_updates): with SMMC_FLAG_STREAM_REF every row is many_updates of the table
+    entries the path's own mt19937 + Lemire map picks -- checked value by value against the oracle's generator."""
+    n, seed0 = 700 + 13, 4000000000
+    traj, final = eng.simulate_keepdata(_sim(n, p, seed0))
+    eng.sync()
+    got = traj.cpu().numpy()
+    want_final, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
+    assert got.shape == (n, p + 1) and np.all(got[:, 0] == np.float32(1000.0))
+    assert np.array_equal(_bits(got[:, -1]), _bits(want_final)) and np.array_equal(_bits(final.cpu().numpy()), _bits(want_final))
+    for i in (0, 1, 63, 64, 255, 256, n - 1):  # rows across waves and workgroups, value by value
+        idx = oracle.mt19937_indices((seed0 + i) & 0xFFFFFFFF, table.size, p)
+        row = oracle.many_updates(1000.0, table[idx], p)
+        assert np.array_equal(_bits(got[i]), _bits(row)), (p, i)
+
+
+def test_trajectories_through_the_redo_path_and_to_host(oracle, monkeypatch):
+    """Rows of paths that reject a generator output come from the generic kernel (T = 12289: a few hundred of
+    4e5 paths): every row's last value is the oracle's final value, and rows are whole (first value the capital,
+    a row equal to many_updates of its own draws for sampled paths incl. every rejecting one found)."""
+    rng = np.random.default_rng(5)
+    big = rng.normal(0.6, 4.3, 12289).astype(np.float32)
+    n, p, seed0 = 400_000, 360, 31337
+    want, _ = oracle.ref_mc_simulations(n, p, 1000.0, big, seed0)
+    for kernel in ("auto", "generic"):
+        e = _engine(big, monkeypatch, SMMC_REF_KERNEL=kernel)
+        try:
+            traj, final = e.simulate_keepdata_to_host(_sim(n, p, seed0))
+            assert np.array_equal(_bits(final), _bits(want)) and np.array_equal(_bits(traj[:, -1]), _bits(want)), kernel
+            assert np.all(traj[:, 0] == np.float32(1000.0))
+            threshold = (2 ** 32 - big.size) % big.size
+            checked = rejecting = 0
+            for i in range(0, n, 401):
+                raw = oracle.mt19937_raw((seed0 + i) & 0xFFFFFFFF, p + 8)
+                low = (raw.astype(np.uint64) * big.size) & 0xFFFFFFFF
+                rejecting += int((low[:p] < threshold).any())
+                idx = oracle.mt19937_indices((seed0 + i) & 0xFFFFFFFF, big.size, p)
+                assert np.array_equal(_bits(traj[i]), _bits(oracle.many_updates(1000.0, big[idx], p))), (kernel, i)
+                checked += 1
+            assert checked > 900
+        finally:
+            e.close()

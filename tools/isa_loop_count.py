@@ -67,7 +67,7 @@ def fingerprint(path, variant, kernel="paths_kernel"):
 # what each workload key of profiles/pmc_traffic.json was measured on: (source file, kernel, template arguments)
 TRAFFIC_KERNELS = {"gaussian": ("smmc_kernels.hip", "paths_kernel", "ILi1ELi0ELb0E"),
                    "table": ("smmc_kernels.hip", "paths_kernel", "ILi0ELi0ELb1E"),
-                   "ref": ("smmc_ref_kernels.hip", "ref_windowed_kernel", "ILi0E")}
+                   "ref": ("smmc_ref_kernels.hip", "ref_windowed_kernel", "ILi0ELb0E")}
 
 
 def source_digest():
