@@ -441,7 +441,7 @@ def main():
     import torch
     import torch.distributed as dist
     import stock_market_monte_carlo_amd as S
-    from stock_market_monte_carlo_amd.dist import gather_stats_records, shard_range
+    from stock_market_monte_carlo_amd.dist import gather_stats_tensor, records_from_tensor, shard_range
     from stock_market_monte_carlo_amd.engine import merge_stats_bytes, stats_from_bytes
 
     n_dev = torch.cuda.device_count()
@@ -497,8 +497,8 @@ def main():
             eng.simulate_to_host(sim, out=host_final)
             return None
         r = eng.simulate(sim, want_final=want_final, want_chunk_stats=want_chunks, want_stats=want_stats, out=final)
-        if want_stats:
-            records = gather_stats_records(r.stats_raw, force=use_dist) if use_dist else None
+        if want_stats:  # the gathered records stay where the collective left them: no host sync inside the step
+            records = gather_stats_tensor(r.stats_raw, force=use_dist) if use_dist else None
         return r
 
     def barrier():
@@ -553,7 +553,7 @@ def main():
     stats = None
     if want_stats and last is not None:
         if use_dist:
-            stats = stats_from_bytes(merge_stats_bytes(records))
+            stats = stats_from_bytes(merge_stats_bytes(records_from_tensor(records)))
         else:
             stats = eng.read_stats(last.stats_raw)
         assert stats.count == n_all, (stats.count, n_all)

@@ -24,23 +24,35 @@ def shard_range(n_total, world, rank):
     return first, count
 
 
-def gather_stats_records(record, group=None, force=False):
+def gather_stats_tensor(record, group=None, force=False):
     """record: uint8 tensor holding this rank's packed statistics record (device tensor
-    under nccl, CPU tensor under gloo).  Returns the list of all ranks' records as bytes,
-    in rank order.  One all_gather (skipped for a one-rank group unless `force`: a one-GPU
-    rehearsal of the collective, bench.py --rehearse-rccl)."""
+    under nccl, CPU tensor under gloo).  ONE all_gather (skipped for a one-rank group unless
+    `force`: a one-GPU rehearsal of the collective, bench.py --rehearse-rccl); returns the
+    gathered tensor [world x record bytes] WHERE THE COLLECTIVE LEFT IT -- under nccl (RCCL) in
+    device memory, enqueued on the current stream, no host synchronisation: a stepping loop
+    can keep launching (the per-step `.cpu()` serialised kernel and collective).
+    records_from_tensor() brings it to the host when someone wants to read it."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if world == 1 and not force:
-        return [record.cpu().numpy().tobytes()]
+        return record.reshape(1, -1)
     if dist.get_backend(group) == "gloo" and record.is_cuda:
         record = record.cpu()  # gloo (CPU rehearsals of the N > 1 path) gathers host tensors
     gathered = torch.empty(world * record.numel(), dtype=torch.uint8, device=record.device)
     dist.all_gather_into_tensor(gathered, record.contiguous(), group=group)
-    raw = gathered.cpu().numpy().tobytes()
-    n = record.numel()
-    return [raw[i * n:(i + 1) * n] for i in range(world)]
+    return gathered.reshape(world, -1)
+
+
+def records_from_tensor(gathered):
+    """The ranks' records as bytes, in rank order (copies to the host: synchronises)."""
+    raw = gathered.cpu().numpy()
+    return [raw[i].tobytes() for i in range(raw.shape[0])]
+
+
+def gather_stats_records(record, group=None, force=False):
+    """gather_stats_tensor + records_from_tensor: the list of all ranks' records as bytes."""
+    return records_from_tensor(gather_stats_tensor(record, group, force))
 
 
 def all_gather_merge_stats(record, group=None):
