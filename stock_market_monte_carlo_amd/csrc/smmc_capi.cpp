@@ -145,7 +145,10 @@ struct smmc_engine {
   uint32_t *d_ref_ws = nullptr;     // the generic kernel's generator states
   uint32_t ref_ws_grid = 0;
   int ref_kernel = 0;               // SMMC_REF_KERNEL: 0 auto, 1 windowed (where it can), 2 generic
-  uint32_t ref_generic_per_cu = 1;  // SMMC_REF_GENERIC_BLOCKS_PER_CU
+  // SMMC_REF_GENERIC_BLOCKS_PER_CU.  2e7 x 1000 paths (profiles/r03/ref_generic_sweep.txt): 1 per CU 85.8 ms, 2 60.0,
+  // 4 48.3, 8 35.0 -- the chains that now supply the seed words want the occupancy; the 1.3 GB of generator
+  // states no longer fit the Infinity Cache, but a path moves 41 % fewer bytes than when its seed words were stored
+  uint32_t ref_generic_per_cu = 8;
 
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;  // pairs: start, stop
@@ -545,7 +548,7 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
   }
   if (const char *env = std::getenv("SMMC_REF_GENERIC_BLOCKS_PER_CU")) {  // tuning knob
     const long v = std::strtol(env, nullptr, 10);
-    if (v >= 1 && v <= 8) e->ref_generic_per_cu = static_cast<uint32_t>(v);
+    if (v >= 1 && v <= 16) e->ref_generic_per_cu = static_cast<uint32_t>(v);
   }
   // dynamic LDS a launch may ask for: the kernels opt in above the 64 KiB default (CDNA4: 160 KiB per CU)
   e->max_lds = std::max<size_t>(prop.sharedMemPerBlock, 128u * 1024u);

@@ -22,9 +22,11 @@
 //     nothing stored, 30-odd VGPRs, full occupancy.
 //   ref_generic_kernel (any length): the classic circular 624-word state, held in a global-memory
 //     workspace laid out [word][lane] so that every access of a wave is one coalesced 256-byte
-//     line; the words a batch of 8 outputs needs are loaded before the batch (none of them is
-//     written inside it), so the loads' latency is paid once per 8 outputs.  One workgroup per CU keeps
-//     the workspace (160 KiB per wave) inside the 256 MiB Infinity Cache.
+//     line -- but only for GENERATED words: the seed words still come from chains (two below output
+//     227, one up to output 623), so a path stores one word per output and loads none, one or two.
+//     From output 624 on the words a batch of 8 outputs needs are loaded before the batch (none of
+//     them is written inside it), so the loads' latency is paid once per 8 outputs.  One workgroup per
+//     CU keeps the workspace (160 KiB per wave) inside the 256 MiB Infinity Cache.
 //
 // Rejections (T / 2^32 per draw: 2.6e-7 for the 1127-entry table) shift a path's later draws by one
 // output.  Generation stays wave-uniform -- every lane generates output j at step j.  In the generic
@@ -245,15 +247,9 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
     const uint64_t item = base + threadIdx.x;
     const bool active = item < count;
     const uint32_t i = !active ? 0u : (k.redo_list ? k.redo_list[item] : static_cast<uint32_t>(item));
-    const uint32_t seed = k.seed0 + i;
-    if (P != 0u) {
-      uint32_t x = seed;
-      W[0] = x;
-      for (uint32_t s = 1; s < kMtN; ++s) {
-        x = mt_seed_step(x, s);
-        W[static_cast<size_t>(s) * L] = x;
-      }
-    }
+    MtWindow w;
+    w.seed = k.seed0 + i;
+    w.x397 = w.seed;
     float total = k.initial_capital;
     uint32_t need = active ? P : 0u;
     float *row = nullptr;
@@ -261,13 +257,57 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
       row = k.d_traj + static_cast<size_t>(i) * (P + 1u);
       if (active) row[0] = total;
     }
-    uint32_t xnh = seed >> 1;  // x[j] >> 1
-    uint32_t s = 0;      // j mod 624; batches of 8 never straddle the wrap (624 = 8 x 78)
+    auto use = [&](uint32_t g) {
+      const bool took = offer<kExactDiv>(k, lds_table, g, total, need);
+      if constexpr (kTraj) {
+        if (took) row[P - need] = total;
+      }
+    };
+    // The seed words x[0 .. 623] are never stored: as in the windowed kernel they come from chains (two
+    // while j < 227, one while j < 623); only generated words x[624 + j] go to the workspace, slot j mod 624.
+    // Against seeding the whole state first this saves 624 stores and 1020 loads per path (41 % of the
+    // traffic of a 1000-period path, which is what bounds this kernel).
+    uint32_t j = 0;
+    if (__any(need != 0u)) {
+      for (uint32_t idx = 1; idx <= kMtM; ++idx) w.x397 = mt_seed_step(w.x397, idx);
+      window_enter_a(w);
+      // outputs 0 .. 226: all three operands are seed words
+      while (j < kMtLag && __any(need != 0u)) {
+        const uint32_t n_here = kMtLag - j < 4u ? kMtLag - j : 4u;
+        for (uint32_t t = 0; t < n_here; ++t) {
+          const uint32_t g = window_next_a(w, j + t, j + t + kMtM + 1u);
+          W[static_cast<size_t>(j + t) * L] = g;
+          use(g);
+        }
+        j += n_here;
+      }
+      // outputs 227 .. 623: x[j + 397] is the generated word of output j - 227; x[j], x[j + 1] stay seed words
+      // until x[624] (output 0) becomes x[j + 1] at j = 623
+      while (j < kMtN && __any(need != 0u)) {
+        const uint32_t n_here = kMtN - j < 4u ? kMtN - j : 4u;
+        uint32_t m[4];
+        for (uint32_t t = 0; t < n_here; ++t) m[t] = W[static_cast<size_t>(j + t - kMtLag) * L];
+        for (uint32_t t = 0; t < n_here; ++t) {
+          const uint32_t g = m[t] ^ mt_twist_term(w.ah, w.a1h, w.a1);
+          w.ah = w.a1h;
+          // x[j + t + 2]: a seed word, or -- the last two outputs of this stretch -- generated word 0 / 1
+          w.a1 = j + t + 2u < kMtN ? mt_seed_step(w.a1, j + t + 2u) : W[static_cast<size_t>(j + t + 2u - kMtN) * L];
+          w.a1h = w.a1 >> 1;
+          W[static_cast<size_t>(j + t) * L] = g;
+          use(g);
+        }
+        j += n_here;
+      }
+    }
+    // outputs 624 ...: every operand is a generated word.  Batches of 8 (624 = 8 x 78: none straddles the wrap),
+    // their 16 operands loaded before the batch (none of them is written inside it)
+    uint32_t xnh = w.ah;  // x[j] >> 1: at j = 624 the stretch above leaves x[624] >> 1 here
+    uint32_t s = 0;       // j mod 624
     auto wrap = [](uint32_t v) { return v >= kMtN ? v - kMtN : v; };
     while (__any(need != 0u)) {
       uint32_t n1[8], m[8];
 #pragma unroll
-      for (uint32_t t = 0; t < 8; ++t) {  // x[j + 1 + t], x[j + 397 + t]: none of them written inside this batch
+      for (uint32_t t = 0; t < 8; ++t) {  // x[j + 1 + t], x[j + 397 + t]
         n1[t] = W[static_cast<size_t>(wrap(s + 1u + t)) * L];
         m[t] = W[static_cast<size_t>(wrap(s + kMtM + t)) * L];
       }
@@ -276,10 +316,7 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
         const uint32_t n1h = n1[t] >> 1;
         const uint32_t g = m[t] ^ mt_twist_term(xnh, n1h, n1[t]);
         W[static_cast<size_t>(s + t) * L] = g;  // x[j + t + 624] takes the place of x[j + t]
-        const bool took = offer<kExactDiv>(k, lds_table, g, total, need);
-        if constexpr (kTraj) {
-          if (took) row[P - need] = total;
-        }
+        use(g);
         xnh = n1h;
       }
       s = wrap(s + 8u);
