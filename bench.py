@@ -255,7 +255,7 @@ def pmc_traffic(mode, n, periods, outputs):
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import isa_loop_count as I
-        if rec.get("source_sha256") != I.source_digest():
+        if rec.get("source_sha256") != I.source_digest(mode):
             return None, f"stale: the kernel sources changed since {rec.get('source')}"
     except Exception as ex:
         return None, f"unverified: {ex}"

@@ -97,7 +97,7 @@ def test_pmc_traffic_belongs_to_the_kernels_as_they_compile_now(asm, tmp_path):
             path = ref_asm
         assert rec["isa_fingerprint"] == I.fingerprint(path, variant, kernel), (
             f"{key}: the kernel changed since the PMC pass ({rec['source']}): run tools/profile_r03.sh again")
-        assert rec["source_sha256"] == I.source_digest(), f"{key}: kernel sources or flags changed since the PMC pass"
+        assert rec["source_sha256"] == I.source_digest(mode), f"{key}: kernel sources or flags changed since the PMC pass"
     b, src = bench.pmc_traffic("gaussian", 100_000_000, 360, "all")
     assert b and src and src.startswith("profiles/")
     # a stale entry is not quoted

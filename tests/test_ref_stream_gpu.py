@@ -224,3 +224,34 @@ def test_trajectories_through_the_redo_path_and_to_host(oracle, monkeypatch):
             assert checked > 900
         finally:
             e.close()
+
+
+def test_full_size_properties_of_the_reference_stream(eng, oracle, table):
+    """BASELINE configs[2] size on the reference's own stream (1e8 paths x 360 periods, 400 MB of final values):
+    what does not need the oracle at that size -- count conservation, statistics against a torch reduction of
+    the final values, bit determinism from run to run, two shards equal to the whole -- and the oracle on the
+    first and last 300 paths and on 300 paths around the 2^27-path launch boundary's place in a longer run."""
+    import torch
+    n, p, seed0 = 100_000_000, 360, 4242
+    r = eng.simulate(_sim(n, p, seed0, n_bins=100, hist_lo=0.0, hist_hi=20000.0), want_stats=True)
+    st = eng.read_stats(r.stats_raw)
+    f = r.final
+    assert st.count == n and int(st.hist.sum()) + st.underflow + st.overflow == n
+    assert st.sum == pytest.approx(float(f.double().sum()), rel=1e-12)
+    assert st.below == int((f < 1000.0).sum()) and st.min == float(f.min()) and st.max == float(f.max())
+    again = eng.simulate(_sim(n, p, seed0)).final
+    assert torch.equal(f.view(torch.int32), again.view(torch.int32))
+    half = 50_000_017
+    a = eng.simulate(_sim(half, p, seed0)).final
+    b = eng.simulate(_sim(n - half, p, seed0, first=half)).final
+    assert torch.equal(torch.cat([a, b]).view(torch.int32), f.view(torch.int32))
+    host = f.cpu().numpy()
+    for first in (0, half - 150, n - 300):
+        want, _ = oracle.ref_mc_simulations(300, p, 1000.0, table, seed0 + first)
+        assert np.array_equal(_bits(host[first:first + 300]), _bits(want)), first
+    # more than one launch per call (2^27 paths each): a short-period run keeps it quick
+    n2 = (1 << 27) + 1000
+    g = eng.simulate(_sim(n2, 2, seed0)).final.cpu().numpy()
+    for first in (0, (1 << 27) - 150, n2 - 300):
+        want, _ = oracle.ref_mc_simulations(300, 2, 1000.0, table, seed0 + first)
+        assert np.array_equal(_bits(g[first:first + 300]), _bits(want)), first

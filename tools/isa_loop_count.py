@@ -70,14 +70,17 @@ TRAFFIC_KERNELS = {"gaussian": ("smmc_kernels.hip", "paths_kernel", "ILi1ELi0ELb
                    "ref": ("smmc_ref_kernels.hip", "ref_windowed_kernel", "ILi0ELb0E")}
 
 
-def source_digest():
-    """sha256 over the kernel sources and the compiler flags: what bench.py can check at run time (no
-    compiler needed) before it quotes a PMC figure."""
+def source_digest(mode):
+    """sha256 over the sources the profiled kernel of workload `mode` is compiled from, and the compiler
+    flags: what bench.py can check at run time (no compiler needed) before it quotes a PMC figure."""
     import hashlib
     sys.path.insert(0, ROOT)
     from stock_market_monte_carlo_amd import build as B
+    names = [TRAFFIC_KERNELS[mode][0], "smmc_device.h", "smmc_internal.h"]
+    if TRAFFIC_KERNELS[mode][0] == "smmc_kernels.hip":
+        names.append("smmc_bm_tables.inc")
     h = hashlib.sha256(" ".join(B.FLAGS).encode())
-    for name in ("smmc_kernels.hip", "smmc_ref_kernels.hip", "smmc_device.h", "smmc_internal.h", "smmc_bm_tables.inc"):
+    for name in names:
         h.update(open(os.path.join(B.CSRC, name), "rb").read())
     return h.hexdigest()
 

@@ -31,7 +31,7 @@ def build_identity(mode):
     src, kernel, variant = I.TRAFFIC_KERNELS[mode]
     asm = I.emit_asm(f"/tmp/pmc_traffic_{os.getpid()}_{src}.s", src)
     return {"kernel": kernel + variant, "isa_fingerprint": I.fingerprint(asm, variant, kernel),
-            "source_sha256": I.source_digest()}
+            "source_sha256": I.source_digest(mode)}
 
 
 def mean_counter(directory, counter, kernel="paths_kernel"):
