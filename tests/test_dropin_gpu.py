@@ -252,3 +252,19 @@ def test_reference_stream_through_the_drop_in(built, oracle, table):
         assert float(m.group(1)) == pytest.approx(w64.mean(), abs=0.006)
         assert float(m.group(2)) == pytest.approx(w64.std(), rel=1e-4)
         assert int(c.group(1).replace(",", "")) == int((big < 1000.0).sum())
+
+
+def test_drop_in_with_the_rccl_merge_gives_the_same_numbers(built):
+    """SMMC_GROUP_MERGE=rccl: the C++ layer's n_gpus calls merge their per-device statistics records through
+    the group's RCCL communicator (one rank on this box) instead of on the host; smmc::mc_summary's record and
+    everything else the check program prints must not change."""
+    n, p = 20000, 36
+    runs = {}
+    for merge in ("host", "rccl"):
+        out = subprocess.check_output([built, str(n), str(p)], cwd=ROOT, env=dict(os.environ, SMMC_GROUP_MERGE=merge),
+                                      timeout=600)
+        runs[merge] = json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1])
+    for key in ("gpu_hash", "cpu_hash", "gauss_hash", "keep_hash", "sum_count", "sum_mean", "sum_below", "hist_total", "quart",
+                "hmean", "hstd", "hbelow"):
+        assert runs["host"][key] == runs["rccl"][key], key
+    assert runs["rccl"]["sum_count"] == n == runs["rccl"]["hist_total"]
