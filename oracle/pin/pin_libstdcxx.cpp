@@ -54,7 +54,9 @@ int main(int argc, char **argv) {
   std::printf("\n ],\n");
   // whole paths: explicit seed, table draw, fund * (100 + r) / 100 in binary32
   std::printf(" \"paths\": [\n");
-  const unsigned periods[] = {1, 4, 360, 1000};
+  // 226 / 227 / 228, 454 / 455, 623 / 624 / 625: the lengths at which the device kernels change how they obtain the
+  // generator's state words (tests/test_ref_stream_gpu.py compares the HIP result with these, not with the oracle)
+  const unsigned periods[] = {1, 4, 226, 227, 228, 360, 454, 455, 623, 624, 625, 1000};
   first = true;
   for (unsigned P : periods)
     for (uint32_t seed0 : {1000u, 4000000000u}) {
@@ -75,6 +77,39 @@ int main(int argc, char **argv) {
       }
       std::printf("]}");
     }
+  std::printf("\n ],\n");
+  // paths in which the real uniform_int_distribution REJECTS a generator output (Lemire's method: 2.6e-7 per draw
+  // for 1127 entries): found by counting the engine calls a path makes.  They pin what happens after a rejection
+  // -- every later draw comes from the next output -- to the library itself.
+  struct Counting {
+    std::mt19937 g;
+    unsigned long calls = 0;
+    using result_type = std::mt19937::result_type;
+    static constexpr result_type min() { return std::mt19937::min(); }
+    static constexpr result_type max() { return std::mt19937::max(); }
+    explicit Counting(uint32_t seed) : g(seed) {}
+    result_type operator()() { ++calls; return g(); }
+  };
+  std::printf(" \"rejecting_paths\": [\n");
+  first = true;
+  for (unsigned P : {360u, 1000u}) {
+    int found = 0;
+    for (uint32_t seed = 0; seed < 4000000u && found < 6; seed++) {
+      Counting rng(seed);
+      std::uniform_int_distribution<int> uni(0, int(table.size()) - 1);
+      float total = 1000.0f;
+      for (unsigned i = 0; i < P; i++) {
+        float a = 100.0f + table[uni(rng)];
+        float m = total * a;
+        total = m / 100.0f;
+      }
+      if (rng.calls == P) continue;
+      std::printf("%s  {\"n_periods\": %u, \"seed\": %u, \"engine_calls\": %lu, \"initial_capital\": 1000.0, \"final_bits\": %u}",
+                  first ? "" : ",\n", P, seed, rng.calls, bits(total));
+      first = false;
+      found++;
+    }
+  }
   std::printf("\n ]\n}\n");
   return 0;
 }

@@ -53,6 +53,21 @@ def test_reference_style_paths_match_libstdcxx(oracle, table):
         assert [int(x) for x in got.view(np.uint32)] == case["final_bits"], case["n_periods"]
 
 
+def test_paths_in_which_the_real_library_rejects_match(oracle, table):
+    """The fixture's `rejecting_paths`: seeds whose path made the system libstdc++'s uniform_int_distribution
+    reject a generator output (one engine call more than periods).  The oracle's hand-written Lemire map must
+    continue exactly as the library does after a rejection."""
+    cases = _pin()["rejecting_paths"]
+    assert len(cases) == 12
+    for c in cases:
+        got, _ = oracle.ref_mc_simulations(1, c["n_periods"], c["initial_capital"], table, c["seed"], n_threads=1)
+        assert int(got.view(np.uint32)[0]) == c["final_bits"], c
+        # and the oracle really rejects there: its index stream consumes one output more than it yields
+        raw = oracle.mt19937_raw(c["seed"], c["engine_calls"])
+        low = (raw.astype(np.uint64) * table.size) & 0xFFFFFFFF
+        assert int((low < (2 ** 32 - table.size) % table.size).sum()) == c["engine_calls"] - c["n_periods"]
+
+
 def test_reference_engine_thread_count_invariant(oracle, table):
     a, _ = oracle.ref_mc_simulations(5000, 36, 1000.0, table, 77, n_threads=1)
     b, used = oracle.ref_mc_simulations(5000, 36, 1000.0, table, 77, n_threads=4)

@@ -47,7 +47,8 @@ def test_golden_paths_of_the_real_libstdcxx(eng, table):
     """HIP result == what std::mt19937 + std::uniform_int_distribution<int> + update_fund gave."""
     pin = json.load(open(os.path.join(HERE, "golden", "libstdcxx_random.json")))
     assert pin["table_len"] == table.size
-    assert sorted({c["n_periods"] for c in pin["paths"]}) == [1, 4, 360, 1000]
+    # 226 .. 228, 454 / 455, 623 .. 625: where the device kernels change how they obtain the generator's words
+    assert sorted({c["n_periods"] for c in pin["paths"]}) == [1, 4, 226, 227, 228, 360, 454, 455, 623, 624, 625, 1000]
     for case in pin["paths"]:
         r = eng.simulate(_sim(32, case["n_periods"], case["seed0"], cap=case["initial_capital"]))
         eng.sync()
@@ -57,6 +58,24 @@ def test_golden_paths_of_the_real_libstdcxx(eng, table):
         r = eng.simulate(_sim(32, case["n_periods"], case["seed0"] - 7, first=7, cap=case["initial_capital"]))
         eng.sync()
         assert [int(x) for x in _bits(r.final.cpu().numpy())] == case["final_bits"]
+
+
+def test_paths_in_which_the_real_library_rejects_an_output(eng, table):
+    """`rejecting_paths` of the fixture: seeds for which the system libstdc++'s uniform_int_distribution rejected
+    a generator output on the way (found by counting engine calls: one more than periods).  On the device such
+    a path is flagged by the windowed kernel and finished by the generic one (360 periods), or runs in the
+    generic kernel from the start (1000): alone, and as lane 17 of a wave of ordinary paths."""
+    pin = json.load(open(os.path.join(HERE, "golden", "libstdcxx_random.json")))
+    cases = pin["rejecting_paths"]
+    assert len(cases) == 12 and {c["n_periods"] for c in cases} == {360, 1000}
+    for c in cases:
+        assert c["engine_calls"] > c["n_periods"]
+        r = eng.simulate(_sim(1, c["n_periods"], c["seed"], cap=c["initial_capital"]))
+        eng.sync()
+        assert int(_bits(r.final.cpu().numpy())[0]) == c["final_bits"], c
+        r = eng.simulate(_sim(64, c["n_periods"], c["seed"] - 17, cap=c["initial_capital"]))
+        eng.sync()
+        assert int(_bits(r.final.cpu().numpy())[17]) == c["final_bits"], c
 
 
 def test_baseline_config0_size_matches_oracle_engine_r(eng, oracle, table):
