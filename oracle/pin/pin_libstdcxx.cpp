@@ -110,6 +110,29 @@ int main(int argc, char **argv) {
       found++;
     }
   }
+  std::printf("\n ],\n");
+  // whole trajectories as mc_simulations_keepdata forms them (src/simulations.cpp:175-186): the returns of
+  // sample_returns_historical (:95-112: mt19937 + uniform_int_distribution, .at(idx)), then many_updates
+  std::printf(" \"trajectories\": [\n");
+  first = true;
+  for (unsigned P : {40u, 360u})
+    for (uint32_t seed : {1000u, 4294967295u, 32569u}) {  // 32569: a path that rejects an output within 360 draws
+      std::mt19937 rng(seed);
+      std::uniform_int_distribution<int> uni(0, int(table.size()) - 1);
+      std::vector<float> returns;
+      for (unsigned i = 0; i < P; i++) returns.push_back(table.at(uni(rng)));
+      std::printf("%s  {\"n_periods\": %u, \"seed\": %u, \"initial_capital\": 1000.0, \"value_bits\": [%u", first ? "" : ",\n", P, seed,
+                  bits(1000.0f));
+      first = false;
+      float total = 1000.0f;
+      for (unsigned i = 0; i < P; i++) {
+        float a = 100.0f + returns[i];
+        float m = total * a;
+        total = m / 100.0f;
+        std::printf(",%u", bits(total));
+      }
+      std::printf("]}");
+    }
   std::printf("\n ]\n}\n");
   return 0;
 }

@@ -68,6 +68,15 @@ def test_paths_in_which_the_real_library_rejects_match(oracle, table):
         assert int((low < (2 ** 32 - table.size) % table.size).sum()) == c["engine_calls"] - c["n_periods"]
 
 
+def test_trajectories_match_libstdcxx(oracle, table):
+    """`trajectories` of the fixture (mc_simulations_keepdata's sample_returns_historical + many_updates, computed by the
+    system libstdc++): the oracle's index stream + many_updates give every value."""
+    for c in _pin()["trajectories"]:
+        idx = oracle.mt19937_indices(c["seed"], table.size, c["n_periods"])
+        row = oracle.many_updates(c["initial_capital"], table[idx], c["n_periods"])
+        assert [int(x) for x in row.view(np.uint32)] == c["value_bits"], (c["n_periods"], c["seed"])
+
+
 def test_reference_engine_thread_count_invariant(oracle, table):
     a, _ = oracle.ref_mc_simulations(5000, 36, 1000.0, table, 77, n_threads=1)
     b, used = oracle.ref_mc_simulations(5000, 36, 1000.0, table, 77, n_threads=4)

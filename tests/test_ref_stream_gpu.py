@@ -217,6 +217,20 @@ def test_trajectories_of_the_reference_stream(eng, oracle, table, p):
         assert np.array_equal(_bits(got[i]), _bits(row)), (p, i)
 
 
+def test_trajectories_of_the_real_libstdcxx(eng, table):
+    """The fixture's `trajectories`: sample_returns_historical + many_updates as mc_simulations_keepdata runs them
+    (src/simulations.cpp:95-112, 175-186), computed by the system libstdc++ -- every value of the row, incl. a path
+    that rejects an output (seed 32569) and the largest 32-bit seed."""
+    pin = json.load(open(os.path.join(HERE, "golden", "libstdcxx_random.json")))
+    assert len(pin["trajectories"]) == 6
+    for c in pin["trajectories"]:
+        traj, final = eng.simulate_keepdata(_sim(3, c["n_periods"], c["seed"] - 1, cap=c["initial_capital"]))
+        eng.sync()
+        row = traj.cpu().numpy()[1]  # path id 1 of seed - 1
+        assert [int(x) for x in _bits(row)] == c["value_bits"], (c["n_periods"], c["seed"])
+        assert int(_bits(final.cpu().numpy())[1]) == c["value_bits"][-1]
+
+
 def test_trajectories_through_the_redo_path_and_to_host(oracle, monkeypatch):
     """Rows of paths that reject a generator output come from the generic kernel (T = 12289: a few hundred of
     4e5 paths): every row's last value is the oracle's final value, and rows are whole (first value the capital,
