@@ -127,3 +127,43 @@ def test_random_host_pipeline_chunks(oracle, monkeypatch):
                 assert np.array_equal(st.hist, o["hist"]), (_brief(c), chunk)
         finally:
             eng.close()
+
+
+def test_random_reference_stream_cases(oracle):
+    """The reference CPU engine's own stream (SMMC_FLAG_STREAM_REF) on 80 random cases: path counts, lengths on both
+    sides of the windowed kernel's limits, table sizes from 1 entry (every draw index 0) to 16384 (no rejections at
+    all: 2^32 is a multiple of it), seeds and path offsets that wrap past 2^32, capitals, both divides -- final values
+    and, every fourth case, whole trajectories, bit for bit against oracle engine (R) and its index stream."""
+    import stock_market_monte_carlo_amd as S
+    rng = np.random.default_rng(3035)
+    eng = S.Engine(0)
+    try:
+        for i in range(80):
+            t_len = int(rng.choice([1, 2, 3, 17, 255, 1127, 2048, 4097, 12289, 16384]))
+            table = rng.normal(0.6, 4.3, t_len).astype(np.float32)
+            n = int(rng.choice([1, 63, 64, 65, 255, 256, 257, 1000, 2049, 5003]))
+            p = int(rng.choice([0, 1, 2, 3, 31, 32, 33, 226, 227, 228, 360, 453, 454, 455, 700]))
+            seed = int(rng.integers(0, 1 << 63))
+            first = int(rng.choice([0, 1, 255, (1 << 32) - 300, (1 << 32), (1 << 45) + 12345]))
+            cap = float(rng.choice([1.0, 1000.0, 12345.678, 1e9]))
+            exact = bool(rng.integers(3) == 0)
+            eng.set_table(table)
+            sim = S.Engine.make_sim(n, p, S.MODE_TABLE, seed, first_path=first, initial_capital=cap, exact_div=exact,
+                                    stream="ref")
+            brief = dict(i=i, t_len=t_len, n=n, p=p, seed=seed, first=first, cap=cap, exact=exact)
+            seed0 = (seed + first) & 0xFFFFFFFF
+            want, _ = oracle.ref_mc_simulations(n, p, cap, table, seed0)
+            if i % 4 == 3:
+                traj, fin = eng.simulate_keepdata(sim)
+                eng.sync()
+                got, rows = fin.cpu().numpy(), traj.cpu().numpy()
+                for k in {0, n // 2, n - 1}:
+                    idx = oracle.mt19937_indices((seed0 + k) & 0xFFFFFFFF, t_len, p)
+                    assert np.array_equal(rows[k].view(np.uint32), oracle.many_updates(cap, table[idx], p).view(np.uint32)), (brief, k)
+            else:
+                r = eng.simulate(sim)
+                eng.sync()
+                got = r.final.cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), brief
+    finally:
+        eng.close()
