@@ -470,8 +470,11 @@ extern "C" {
 
 int smmc_abi_version(void) { return SMMC_ABI_VERSION; }
 const char *smmc_last_error(void) { return g_err; }
-// for the library's other translation units (smmc_group.cpp): the calling thread's error text
-int smmc_set_error_(int code, const char *message) { return fail(code, "%s", message ? message : ""); }
+// for the library's other translation units (smmc_group.cpp): the calling thread's error text.  Not part of the
+// ABI: hidden, so that libsmmc_hip.so exports exactly what include/smmc.h declares besides the C++ drop-in layer.
+__attribute__((visibility("hidden"))) int smmc_set_error_(int code, const char *message) {
+  return fail(code, "%s", message ? message : "");
+}
 
 float smmc_update_fund(float fund_value, float period_return) {
   // reference src/simulations.cpp:14-16; this TU is built with -ffp-contract=off

@@ -81,7 +81,7 @@ Rccl &rccl() {
 }  // namespace
 
 // smmc_capi.cpp: stores a message for smmc_last_error() of the calling thread
-extern "C" int smmc_set_error_(int code, const char *message);
+extern "C" __attribute__((visibility("hidden"))) int smmc_set_error_(int code, const char *message);
 
 namespace {
 

@@ -29,6 +29,13 @@ def test_every_declared_symbol_is_exported(L):
     for name in declared:
         assert hasattr(L, name), name
     assert L.smmc_abi_version() == _lib.ABI_VERSION == 3
+    # and nothing else with the C ABI's prefix leaves the library (helpers shared between its translation
+    # units are hidden)
+    import subprocess
+    from stock_market_monte_carlo_amd import build
+    out = subprocess.check_output(["nm", "-D", "--defined-only", build.LIB]).decode()
+    exported = {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T" and ln.split()[2].startswith("smmc_")}
+    assert exported == declared, exported ^ declared
 
 
 def test_struct_layout_matches_header(L):
