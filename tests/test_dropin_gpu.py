@@ -268,3 +268,16 @@ def test_drop_in_with_the_rccl_merge_gives_the_same_numbers(built):
                 "hmean", "hstd", "hbelow"):
         assert runs["host"][key] == runs["rccl"][key], key
     assert runs["rccl"]["sum_count"] == n == runs["rccl"]["hist_total"]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "benchmark_reduce_mean")),
+                    reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_reference_reduce_mean_program_compiled_unmodified_runs_on_the_drop_in():
+    """examples/benchmark_reduce_mean.cpp of the reference, compiled untouched against this
+    header and library: its own CPU check and reduce_mean_gpu print the same mean."""
+    env = dict(os.environ, LOCPATH=os.path.join(REF_DIR, "locale"))
+    r = subprocess.run([os.path.join(REF_DIR, "benchmark_reduce_mean"), "5000000"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"mean_cpu: ([0-9.]+) \| mean_gpu: ([0-9.]+)", r.stdout)
+    assert m and m.group(1) == m.group(2) == "2499999.50", r.stdout
