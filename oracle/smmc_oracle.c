@@ -17,6 +17,12 @@
  *       calls at src/simulations.cpp:245-247) against the system libstdc++ 11.4
  *       through oracle/pin/pin_libstdcxx.cpp -> tests/golden/libstdcxx_*.json,
  *       and the ISO C++ known answer (10000th output of mt19937() == 4123659995);
+ *       the same fixture holds whole reference-style paths at the device kernels' edge
+ *       lengths, paths in which the library REJECTS a generator output, and whole
+ *       keepdata trajectories -- engine (R) below reproduces all of them, and since
+ *       round 3 so do the HIP kernels of the reference's own stream
+ *       (SMMC_FLAG_STREAM_REF; tests/test_ref_stream_gpu.py compares them with the
+ *       fixture directly, not through this file);
  *     - Philox4x32-10 against the published Random123 known-answer vectors;
  *     - the statistics record (sum, mean, below-count) against update_mean_std /
  *       update_count_below_min compiled from the reference's examples/benchmark_mc_gpu.cpp
