@@ -300,10 +300,16 @@ void size_result_and_warm(std::vector<float> &totals, long n_total, int n_gpus, 
     }
     t_warm = seconds_since(t0);
   });
-  resize_prefaulted_impl(totals, static_cast<size_t>(n_total));
-  const double t_sized = seconds_since(t0);
-  pinned.pin(totals);
-  const double t_pinned = seconds_since(t0);
+  double t_sized = 0.0, t_pinned = 0.0;
+  try {
+    resize_prefaulted_impl(totals, static_cast<size_t>(n_total));
+    t_sized = seconds_since(t0);
+    pinned.pin(totals);
+    t_pinned = seconds_since(t0);
+  } catch (...) {  // e.g. std::bad_alloc for the result: the helper thread must be joined before the stack unwinds
+    warm.join();
+    throw;
+  }
   warm.join();
   if (warm_error) std::rethrow_exception(warm_error);
   if (verbose())
