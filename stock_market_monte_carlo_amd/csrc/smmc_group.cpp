@@ -130,6 +130,25 @@ struct ShardProgress {  // one per device and call: deltas go to the call's tota
   }
 };
 
+// fn(i) for i = 0 .. n - 1, one host thread each (the calling thread alone when n == 1).  False if a thread
+// could not be started: those that were are joined first, the others' work was not done.
+template <typename Fn>
+bool run_on_threads(int n, Fn fn) {
+  if (n == 1) {
+    fn(0);
+    return true;
+  }
+  std::vector<std::thread> threads;
+  bool ok = true;
+  try {
+    for (int i = 0; i < n; ++i) threads.emplace_back(fn, i);
+  } catch (...) {
+    ok = false;
+  }
+  for (auto &t : threads) t.join();
+  return ok;
+}
+
 void shard_of(uint64_t n, int n_dev, int index, uint64_t *first, uint64_t *count) {
   const uint64_t base = n / n_dev, extra = n % n_dev, i = static_cast<uint64_t>(index);
   *first = base * i + (i < extra ? i : extra);
@@ -172,12 +191,9 @@ int smmc_group_create(const int *devices, int n_devices, int merge, smmc_group *
     }
     if (rcs[i] != SMMC_OK) errs[i] = smmc_last_error();
   };
-  if (n_devices == 1) {
-    make(0);
-  } else {
-    std::vector<std::thread> threads;
-    for (int i = 0; i < n_devices; ++i) threads.emplace_back(make, i);
-    for (auto &t : threads) t.join();
+  if (!run_on_threads(n_devices, make)) {
+    smmc_group_destroy(g);
+    return fail(SMMC_ERR_NOMEM, "could not start the host threads that create the engines");
   }
   g->engines_ms = ms_since(t0);
   for (int i = 0; i < n_devices; ++i)
@@ -269,13 +285,7 @@ int smmc_group_prepare_host(smmc_group *g, uint64_t n_paths) {
     rcs[i] = smmc_engine_prepare_host(g->engines[i], count);
     if (rcs[i] != SMMC_OK) errs[i] = smmc_last_error();
   };
-  if (G == 1) {
-    run(0);
-  } else {
-    std::vector<std::thread> threads;
-    for (int i = 0; i < G; ++i) threads.emplace_back(run, i);
-    for (auto &t : threads) t.join();
-  }
+  if (!run_on_threads(G, run)) return fail(SMMC_ERR_NOMEM, "could not start a host thread per device");
   for (int i = 0; i < G; ++i)
     if (rcs[i] != SMMC_OK) return fail(rcs[i], "device %d: %s", g->devices[i], errs[i].c_str());
   return SMMC_OK;
@@ -384,14 +394,9 @@ int smmc_group_simulate(smmc_group *g, const smmc_sim *sim, float *host_final, f
       std::fprintf(stderr, "smmc: shard %d on device %d: paths [%llu, %llu): simulate+copy %.3f s\n", i, g->devices[i],
                    static_cast<unsigned long long>(first), static_cast<unsigned long long>(first + count), ms_since(t0) / 1e3);
   };
-  if (G == 1) {
-    run(0);
-  } else {
-    std::vector<std::thread> threads;
-    for (int i = 0; i < G; ++i) threads.emplace_back(run, i);
-    for (auto &t : threads) t.join();
-  }
+  const bool started = run_on_threads(G, run);
   if (pinned) (void)hipHostUnregister(pinned);
+  if (!started) return fail(SMMC_ERR_NOMEM, "could not start a host thread per device");
   for (int i = 0; i < G; ++i)
     if (rcs[i] != SMMC_OK) return fail(rcs[i], "shard %d on device %d: %s", i, g->devices[i], errs[i].c_str());
   if (verbose_env() && !(sim->flags & SMMC_FLAG_QUIET))
