@@ -460,44 +460,32 @@ def read_historical_returns(csv_fpath):
     return np.array(vals, dtype=np.float32)
 
 
+_groups = {}
+
+
+def _group(devices):
+    """One cached Group (smmc_group_*, host merge) per device list, like the C++ layer's."""
+    key = tuple(devices)
+    g = _groups.get(key)
+    if g is None:
+        g = _groups[key] = Group(list(devices))
+    return g
+
+
 def mc_simulations_gpu(max_n_simulations, n_periods, initial_capital, returns, n_gpus=1, seed=None, stream=3):
     """simulations.h:73-79, src/simulations.cu:661-680: final value of every path (host array).
     stream: 3 (default) / 2 the build's counter streams; "ref" the reference CPU engine's own stream --
     path id draws from mt19937(seed + id) through libstdc++'s uniform_int_distribution.
-    Paths shard over n_gpus devices of this process by contiguous global id ranges, one host thread
-    per shard so that all devices compute and copy at once (the reference's async launcher,
-    src/simulations.cu:599-626; ctypes releases the GIL for the duration of the call)."""
-    import threading
-    from .dist import shard_range
+    Paths shard over n_gpus devices of this process by contiguous global id ranges through the C entry
+    for several devices (smmc_group_simulate: one host thread per device, so that all devices compute and
+    copy at once -- the reference's async launcher, src/simulations.cu:599-626; the N mod G remainder is
+    kept).  SMMC_DEVICE_MAP="0,0,1" places shard g on device map[g]."""
     devs = _device_map(n_gpus)
-    seed = _seed(seed)
     n = int(max_n_simulations)
-    out = np.empty(n, dtype=np.float32)
-    errors = []
-
-    def run(g):
-        try:
-            first, cnt = shard_range(n, n_gpus, g)
-            import torch
-            with torch.cuda.device(devs[g]):
-                e = _engine(devs[g], devs[:g].count(devs[g]))
-                e.set_table(returns)
-                sim = Engine.make_sim(cnt, n_periods, MODE_TABLE, seed, first_path=first, initial_capital=initial_capital,
-                                      stream=stream)
-                e.simulate_to_host(sim, out=out[first:first + cnt])
-        except Exception as ex:  # re-raised on the calling thread
-            errors.append(ex)
-
-    if n_gpus == 1:
-        run(0)
-    else:
-        threads = [threading.Thread(target=run, args=(g,)) for g in range(n_gpus)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-    if errors:
-        raise errors[0]
+    g = _group(devs)
+    g.set_table(returns)
+    sim = Engine.make_sim(n, n_periods, MODE_TABLE, _seed(seed), initial_capital=initial_capital, stream=stream)
+    out, _, _ = g.simulate(sim)
     return out
 
 
