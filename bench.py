@@ -58,7 +58,7 @@ VALU_INSTS_PER_STEP = {"gaussian": 70 / 4, "table": 84 / 8}  # Gaussian: counter
 VALU_CHECK_PER_STEP = {"gaussian": 2 / 4, "table": 2 / 8}  # the range-checked divide: two compares per Philox block
 # --stream ref (the reference CPU engine's per-path mt19937 stream, ref_windowed_kernel): VALU instructions per
 # step of the 397-step seed run-up, per output below output 227 and per output from 227 on (same ISA test)
-REF_VALU = {"runup_step": 34 / 8, "output_lo": 108 / 4, "output_hi": 142 / 4}
+REF_VALU = {"runup_step": 24 / 8, "output_lo": 100 / 4, "output_hi": 128 / 4}
 REF_WINDOW = (397, 227, 454)  # run-up steps, first output of the second stretch, longest path of the windowed kernel
 
 

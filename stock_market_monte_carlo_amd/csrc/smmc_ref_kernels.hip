@@ -48,7 +48,36 @@ using namespace dev;
 constexpr uint32_t kMtN = 624, kMtM = 397, kMtLag = kMtN - kMtM;  // 227
 
 // x[i] from x[i-1]: the seeding recurrence of ISO C++ [rand.eng.mers] (oracle mt_seed)
-__device__ __forceinline__ uint32_t mt_seed_step(uint32_t x, uint32_t i) { return 1812433253u * (x ^ (x >> 30)) + i; }
+//
+// i is wave-uniform.  The multiply-add is ONE v_mad_u64_u32 -- multiplier in a VGPR (`k`, set up once per kernel by
+// mt_multiplier(): an instruction reads one scalar operand, and that is the 64-bit addend i), the low word of the
+// result taken -- where hipcc, which knows that only the low word is wanted, emits v_mul_lo_u32 + v_add.  On gfx950
+// that pair is much the slower: with 1250 chain steps per 360-period path the exchange took the windowed kernel
+// from 27.4 to 22.5 ms (the same exchange for v_mul_hi_u32 in paths_kernel's table draw changed nothing).
+__device__ __forceinline__ uint32_t mt_multiplier() {
+  uint32_t k = 1812433253u;
+  asm volatile("" : "+v"(k));
+  return k;
+}
+__device__ __forceinline__ uint32_t mt_seed_step(uint32_t x, uint32_t i, uint32_t k) {
+  const uint32_t t = x ^ (x >> 30);
+  uint64_t d, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(t), "v"(k), "s"(static_cast<uint64_t>(i)));
+  return static_cast<uint32_t>(d);
+}
+
+// x[397] from x[0]: the 397-step run-up of the far chain, eight steps per trip (the trip count is hidden from the
+// compiler, which otherwise unrolls all 397 steps: 16 KB of code and an SGPR pair per step's index).
+__device__ __forceinline__ uint32_t mt_run_up(uint32_t seed, uint32_t k) {
+  uint32_t x = seed, idx = 1, last = kMtM;
+  asm("" : "+s"(last));
+  for (; idx + 7u <= last; idx += 8u) {
+#pragma unroll
+    for (uint32_t t = 0; t < 8u; ++t) x = mt_seed_step(x, idx + t, k);
+  }
+  for (; idx <= last; ++idx) x = mt_seed_step(x, idx, k);
+  return x;
+}
 
 // tw(x[n], x[n+1]) of the twist  x[n + 624] = x[n + 397] ^ tw(x[n], x[n+1])  (oracle mt_twist):
 // y = top bit of x[n] with the low 31 of x[n+1]; (y >> 1) ^ (y odd ? 0x9908b0df : 0).  The callers keep
@@ -88,6 +117,7 @@ __device__ __forceinline__ bool offer(const RefArgs &k, const float *lds_table, 
 // The seed words a path's next output needs, as chains advanced in step with the output index j.
 struct MtWindow {
   uint32_t seed, x397;  // x[0], x[397]: where the chains of the second stretch start
+  uint32_t k;           // mt_multiplier()
   uint32_t ah, a1, a1h; // x[j] >> 1, x[j + 1], x[j + 1] >> 1
   uint32_t b;           // j < 227: x[j + 397];  j >= 227: x[j + 170]
   uint32_t ch, c1, c1h; // j >= 227: x[j - 227] >> 1, x[j - 226], x[j - 226] >> 1
@@ -95,7 +125,7 @@ struct MtWindow {
 
 __device__ __forceinline__ void window_enter_a(MtWindow &w) {
   w.ah = w.seed >> 1;
-  w.a1 = mt_seed_step(w.seed, 1u);
+  w.a1 = mt_seed_step(w.seed, 1u, w.k);
   w.a1h = w.a1 >> 1;
   w.b = w.x397;
 }
@@ -104,14 +134,14 @@ __device__ __forceinline__ void window_enter_a(MtWindow &w) {
 __device__ __forceinline__ uint32_t window_next_a(MtWindow &w, uint32_t j, uint32_t far) {  // outputs 0 .. 226
   const uint32_t g = w.b ^ mt_twist_term(w.ah, w.a1h, w.a1);
   w.ah = w.a1h;
-  w.a1 = mt_seed_step(w.a1, j + 2u);
+  w.a1 = mt_seed_step(w.a1, j + 2u, w.k);
   w.a1h = w.a1 >> 1;
-  w.b = mt_seed_step(w.b, far);
+  w.b = mt_seed_step(w.b, far, w.k);
   return g;
 }
 __device__ __forceinline__ void window_enter_b(MtWindow &w) {
   w.ch = w.seed >> 1;
-  w.c1 = mt_seed_step(w.seed, 1u);
+  w.c1 = mt_seed_step(w.seed, 1u, w.k);
   w.c1h = w.c1 >> 1;
   w.b = w.x397;
 }
@@ -120,12 +150,12 @@ __device__ __forceinline__ uint32_t window_next_b(MtWindow &w, uint32_t j, uint3
   // x[j + 397] = x[624 + (j - 227)] = x[j + 170] ^ tw(x[j - 227], x[j - 226]): output j - 227 again
   const uint32_t g = xor3(w.b, mt_twist_term(w.ch, w.c1h, w.c1), mt_twist_term(w.ah, w.a1h, w.a1));
   w.ah = w.a1h;
-  w.a1 = mt_seed_step(w.a1, j + 2u);
+  w.a1 = mt_seed_step(w.a1, j + 2u, w.k);
   w.a1h = w.a1 >> 1;
   w.ch = w.c1h;
-  w.c1 = mt_seed_step(w.c1, near);
+  w.c1 = mt_seed_step(w.c1, near, w.k);
   w.c1h = w.c1 >> 1;
-  w.b = mt_seed_step(w.b, far);
+  w.b = mt_seed_step(w.b, far, w.k);
   return g;
 }
 
@@ -165,14 +195,16 @@ __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
   __syncthreads();
   float *const tile = lds_table + ((k.table_len + 3u) & ~3u) + (threadIdx.x >> 6) * kTrajTileWords;  // kTraj only
   constexpr bool kExactDiv = kDiv == kDivExact;
+  const uint32_t kmul = mt_multiplier();
   const uint32_t P = k.n_periods;  // <= ref_windowed_max_outputs()
   const uint32_t n_chunks = (k.n_paths + kBlock - 1u) / kBlock;  // n_paths <= 2^31
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t i = chunk * kBlock + threadIdx.x;
     MtWindow w;
+    w.k = kmul;
     w.seed = k.seed0 + i;
     w.x397 = w.seed;
-    for (uint32_t idx = 1; idx <= kMtM; ++idx) w.x397 = mt_seed_step(w.x397, idx);
+    w.x397 = mt_run_up(w.seed, w.k);
     window_enter_a(w);
     w.ch = w.c1 = w.c1h = 0u;
     float total = k.initial_capital;
@@ -243,11 +275,13 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
   uint32_t *const W = k.workspace + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   const uint32_t count = k.redo_list ? *k.redo_count : k.n_paths;
   const uint32_t P = k.n_periods;
+  const uint32_t kmul = mt_multiplier();
   for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kBlock; base < count; base += L) {
     const uint64_t item = base + threadIdx.x;
     const bool active = item < count;
     const uint32_t i = !active ? 0u : (k.redo_list ? k.redo_list[item] : static_cast<uint32_t>(item));
     MtWindow w;
+    w.k = kmul;
     w.seed = k.seed0 + i;
     w.x397 = w.seed;
     float total = k.initial_capital;
@@ -269,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
     // traffic of a 1000-period path, which is what bounds this kernel).
     uint32_t j = 0;
     if (__any(need != 0u)) {
-      for (uint32_t idx = 1; idx <= kMtM; ++idx) w.x397 = mt_seed_step(w.x397, idx);
+      w.x397 = mt_run_up(w.seed, w.k);
       window_enter_a(w);
       // outputs 0 .. 226: all three operands are seed words
       while (j < kMtLag && __any(need != 0u)) {
@@ -291,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
           const uint32_t g = m[t] ^ mt_twist_term(w.ah, w.a1h, w.a1);
           w.ah = w.a1h;
           // x[j + t + 2]: a seed word, or -- the last two outputs of this stretch -- generated word 0 / 1
-          w.a1 = j + t + 2u < kMtN ? mt_seed_step(w.a1, j + t + 2u) : W[static_cast<size_t>(j + t + 2u - kMtN) * L];
+          w.a1 = j + t + 2u < kMtN ? mt_seed_step(w.a1, j + t + 2u, w.k) : W[static_cast<size_t>(j + t + 2u - kMtN) * L];
           w.a1h = w.a1 >> 1;
           W[static_cast<size_t>(j + t) * L] = g;
           use(g);
