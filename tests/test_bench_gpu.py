@@ -100,3 +100,18 @@ def test_two_ranks_config4_host_buffers_equal_the_halves_of_the_one_rank_run():
     assert len(two["host_digests"]) == 2 and two["host_digests"] == one["host_digests"]
     assert two["host_digests"][0] != two["host_digests"][1]
     assert two["host_pipeline"]["bytes_to_host_per_step"] == 4.0 * 1_000_001
+
+
+def test_four_self_launched_ranks_config3_remainder_and_merge():
+    """Four ranks (four processes on this box's one GPU; the pool allows six) over an N that is not a
+    multiple of four: every rank's id range, the remainder, and the merged record equal to one rank's."""
+    total = 4_000_003
+    four = _run("--gpus", "4", "--backend", "gloo", "--config", "3", "--total-paths", str(total), "--steps", "2",
+                "--warmup", "1", timeout=600)
+    one = _run("--config", "3", "--total-paths", str(total), "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert four["n_gpus"] == 4 and four["ranks"] == 4 and len(four["devices"]) == 4
+    assert four["config"]["paths_all_ranks"] == total and four["config"]["paths_rank0"] == 1_000_001
+    assert four["result"]["hist_total"] == one["result"]["hist_total"] == total
+    assert four["result"]["below_initial"] == one["result"]["below_initial"]
+    assert four["result"]["mean"] == pytest.approx(one["result"]["mean"], rel=1e-12)
+    assert four["result"]["std"] == pytest.approx(one["result"]["std"], rel=1e-10)

@@ -24,7 +24,7 @@ def _json_lines(stdout):
     return [json.loads(l) for l in stdout.splitlines() if l.startswith("{")]
 
 
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 8])  # 8 = the rank count of the driver's SCALE run
 def test_plain_invocation_launches_its_own_ranks(n):
     r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--backend", "gloo", "--launch-check"], cwd=ROOT,
                        env=_env(), capture_output=True, text=True, timeout=300)

@@ -118,6 +118,24 @@ def test_benchmark_mc_gpu_three_shards_on_one_gpu(built):
         assert r.returncode == 1 and "exceeds the visible devices" in r.stderr
 
 
+@pytest.mark.parametrize("periods", [360, 1000])
+def test_benchmark_mc_gpu_eight_shards_as_configs_3_and_4_name_them(built, periods):
+    """`benchmark_mc_gpu 8 <P> <N>`: the command line BASELINE configs[3] / configs[4] would be run with on an
+    8-GPU node, all eight shards on this box's one GPU (eight engines, eight host threads, one process):
+    mean and count as the one-shard run prints them, the remainder of N mod 8 kept (reference drops it,
+    src/simulations.cu:602-603)."""
+    n = 800005
+    eight_map = ",".join(["0"] * 8)
+    one = _run("benchmark_mc_gpu", 1, periods, n, env={"SMMC_JSON": "1"})
+    eight = _run("benchmark_mc_gpu", 8, periods, n, env={"SMMC_DEVICE_MAP": eight_map, "SMMC_JSON": "1", "SMMC_VERBOSE": "1"})
+    assert one.returncode == 0 and eight.returncode == 0, eight.stderr
+    pick = lambda out: [l for l in out.splitlines() if l.startswith("mean:") or l.startswith("count_below")]  # noqa: E731
+    assert pick(one.stdout) == pick(eight.stdout) and len(pick(one.stdout)) == 2
+    assert f"All {n} simulation done" in eight.stdout
+    assert eight.stderr.count("smmc: shard") == 8
+    assert "paths [0, 100001)" in eight.stderr and f"paths [700005, {n})" in eight.stderr  # five shards carry one extra path
+
+
 def test_python_mc_simulations_gpu_shards_concurrently(table, monkeypatch):
     import stock_market_monte_carlo_amd as S
     monkeypatch.setenv("SMMC_DEVICE_MAP", "0,0,0")
