@@ -115,3 +115,30 @@ def test_four_self_launched_ranks_config3_remainder_and_merge():
     assert four["result"]["below_initial"] == one["result"]["below_initial"]
     assert four["result"]["mean"] == pytest.approx(one["result"]["mean"], rel=1e-12)
     assert four["result"]["std"] == pytest.approx(one["result"]["std"], rel=1e-10)
+
+
+def test_ranks_made_by_torchrun_run_the_real_step():
+    """The driver's N > 1 command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` -- with the real step (both ranks on this
+    box's one GPU, hence gloo for the record gather): ONE JSON line from rank 0, launcher "external", the
+    merged record equal to one rank's."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    total = 3_000_001
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--backend", "gloo",
+                        "--config", "3", "--total-paths", str(total), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    two = json.loads(lines[0])
+    one = _run("--config", "3", "--total-paths", str(total), "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert two["launcher"] == "external" and two["ranks"] == 2 and two["n_gpus"] == 2 and two["backend"] == "gloo"
+    assert two["config"]["paths_all_ranks"] == total and two["config"]["paths_rank0"] == 1_500_001
+    assert two["result"]["hist_total"] == one["result"]["hist_total"] == total
+    assert two["result"]["below_initial"] == one["result"]["below_initial"]
+    assert two["result"]["mean"] == pytest.approx(one["result"]["mean"], rel=1e-12)
