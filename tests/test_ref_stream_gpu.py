@@ -105,7 +105,7 @@ def test_baseline_config0_size_matches_oracle_engine_r(eng, oracle, table):
 # from 455 on the generic kernel runs; 624/625: the state wraps
 @pytest.mark.parametrize("p", [0, 1, 2, 7, 8, 9, 226, 227, 228, 229, 360, 437, 438, 439, 453, 454, 455, 623, 624, 625, 1000, 1300])
 def test_every_length_both_kernels(eng, oracle, table, p):
-    n, seed0 = 2000 + 77, 4000000000  # ragged; seeds wrap past 2^32 inside the launch window
+    n, seed0 = 2000 + 77, 2 ** 32 - 1000  # ragged; the seeds seed0 + id wrap past 2^32 inside the launch (path 1000 has seed 0)
     want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
     r = eng.simulate(_sim(n, p, seed0))
     eng.sync()
@@ -204,14 +204,14 @@ def test_trajectories_of_the_reference_stream(eng, oracle, table, p):
     """mc_simulations_keepdata draws like mc_simulations (src/simulations.cpp:175-186: a generator per path,
     sample_returns_historical, many_updates): with SMMC_FLAG_STREAM_REF every row is many_updates of the table
     entries the path's own mt19937 + Lemire map picks -- checked value by value against the oracle's generator."""
-    n, seed0 = 700 + 13, 4000000000
+    n, seed0 = 700 + 13, 2 ** 32 - 300  # the seeds wrap past 2^32 at path 300
     traj, final = eng.simulate_keepdata(_sim(n, p, seed0))
     eng.sync()
     got = traj.cpu().numpy()
     want_final, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
     assert got.shape == (n, p + 1) and np.all(got[:, 0] == np.float32(1000.0))
     assert np.array_equal(_bits(got[:, -1]), _bits(want_final)) and np.array_equal(_bits(final.cpu().numpy()), _bits(want_final))
-    for i in (0, 1, 63, 64, 255, 256, n - 1):  # rows across waves and workgroups, value by value
+    for i in (0, 1, 63, 64, 255, 256, 299, 300, n - 1):  # rows across waves, workgroups and the seed wrap, value by value
         idx = oracle.mt19937_indices((seed0 + i) & 0xFFFFFFFF, table.size, p)
         row = oracle.many_updates(1000.0, table[idx], p)
         assert np.array_equal(_bits(got[i]), _bits(row)), (p, i)
