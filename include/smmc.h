@@ -365,6 +365,15 @@ uint64_t smmc_stats_bytes(uint32_t n_bins);
  * shards in ascending rank order gives a result independent of timing. */
 int smmc_stats_merge(void *dst_packed, const void *src_packed);
 
+/* ---- the reference's device demo ------------------------------------------------ */
+
+/* vector_add_gpu, src/gpu.cu:17-47 (kernel impl_vector_add_gpu :8-14): out[i] = a[i] + b[i] for three HOST
+ * arrays of n floats, computed on the current device (H2D of a and b, one launch, D2H of out; device
+ * memory is allocated and freed inside the call, as in the reference).  north_star names the file beside
+ * the engine; it is not part of the hot path.  kernel_seconds (optional): the launch alone, by HIP events
+ * -- the figure the reference prints as "GPU time".  n == 0 is a no-op; SMMC_ERR_NO_DEVICE without a GPU. */
+int smmc_vector_add(float *out, const float *a, const float *b, int64_t n, double *kernel_seconds);
+
 #ifdef __cplusplus
 }
 #endif

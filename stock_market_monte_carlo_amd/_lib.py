@@ -72,6 +72,7 @@ SYMBOLS = [
     ("smmc_update_fund", C.c_float, [C.c_float, C.c_float]),
     ("smmc_many_updates", None, [C.c_void_p, C.c_void_p, C.c_uint32]),
     ("smmc_abi_version", C.c_int, []),
+    ("smmc_vector_add", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
     ("smmc_last_error", C.c_char_p, []),
     ("smmc_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("smmc_engine_create", C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libsmmc_hip.so")
 
-SOURCES = ["smmc_kernels.hip", "smmc_ref_kernels.hip", "smmc_stats_kernels.hip", "smmc_capi.cpp", "smmc_group.cpp", "smmc_dropin.cpp"]
+SOURCES = ["smmc_kernels.hip", "smmc_ref_kernels.hip", "smmc_stats_kernels.hip", "smmc_vector_add.hip", "smmc_capi.cpp", "smmc_group.cpp", "smmc_dropin.cpp"]
 HEADERS = [os.path.join(CSRC, "smmc_internal.h"), os.path.join(CSRC, "smmc_device.h"), os.path.join(CSRC, "smmc_bm_tables.inc"),
            os.path.join(CSRC, "smmc_synthetic_table.inc"), os.path.join(ROOT, "include", "smmc.h"),
            os.path.join(ROOT, "include", "stock_market_monte_carlo", "simulations.h")]

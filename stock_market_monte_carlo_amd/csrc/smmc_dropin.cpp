@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +28,7 @@
 #include <unistd.h>
 
 #include "smmc.h"
+#include "stock_market_monte_carlo/gpu.h"
 
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23  // Linux 5.14
@@ -470,6 +472,20 @@ float reduce_mean_gpu(std::vector<float> &vec, long n) {
 }
 
 // ---- CSV writers (src/helpers.cpp) ------------------------------------------------------------------
+
+// ---- include/stock_market_monte_carlo/gpu.h: the reference's vector-add demo ----------------------
+
+void vector_add(float *out, float *a, float *b, int n) {  // src/gpu.cpp:7-15
+  const std::clock_t start = std::clock();
+  for (int i = 0; i < n; i++) out[i] = a[i] + b[i];
+  std::printf("CPU time: %f\n", static_cast<double>(std::clock() - start) / CLOCKS_PER_SEC);
+}
+
+void vector_add_gpu(float *out, float *a, float *b, int n) {  // src/gpu.cu:17-47
+  double seconds = 0.0;
+  if (smmc_vector_add(out, a, b, n, &seconds) != SMMC_OK) throw std::runtime_error(smmc_last_error());
+  std::printf("GPU time: %f\n", seconds);
+}
 
 void print_vector(std::vector<float> &v) {
   std::printf("v = [ ");

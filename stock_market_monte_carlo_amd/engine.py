@@ -534,6 +534,20 @@ def reduce_mean_gpu(vec, n=None):
     return _engine(0).reduce_mean_host(v[:n])[0]
 
 
+def vector_add_gpu(a, b):
+    """out = a + b for two host float arrays on the MI355X (src/gpu.cu:17-47, include/.../gpu.h:2; the
+    demo north_star names beside the engine).  Returns (out, seconds of the launch alone)."""
+    x = np.ascontiguousarray(a, dtype=np.float32)
+    y = np.ascontiguousarray(b, dtype=np.float32)
+    if x.shape != y.shape or x.ndim != 1:
+        raise ValueError("vector_add_gpu takes two 1-D arrays of one length")
+    out = np.empty_like(x)
+    sec = C.c_double()
+    _lib.check(_lib.lib().smmc_vector_add(out.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
+                                          y.ctypes.data_as(C.c_void_p), x.size, C.byref(sec)))
+    return out, sec.value
+
+
 def _to_device(values, n_el):
     import torch
     v = np.ascontiguousarray(values, dtype=np.float32)[: int(n_el)]

@@ -1,5 +1,5 @@
 // launch_stubs.cpp -- CPU sanitizer builds only (make -C oracle asan / tsan): stands in for the
-// HIP translation units of THIS repository (csrc/smmc_kernels.hip, smmc_ref_kernels.hip, smmc_stats_kernels.hip), whose device
+// HIP translation units of THIS repository (csrc/smmc_kernels.hip, smmc_ref_kernels.hip, smmc_stats_kernels.hip, smmc_vector_add.hip), whose device
 // code g++ cannot compile, so that the host-side product code (csrc/smmc_capi.cpp, smmc_dropin.cpp) links
 // and its no-GPU paths can run under ASan / UBSan / TSan.  Every launch reports "no device".
 #include "smmc_internal.h"
@@ -30,3 +30,6 @@ hipError_t launch_ref_generic(const RefArgs &, bool, uint32_t, hipStream_t) { re
 hipError_t launch_chunk_stats(const float *, uint64_t, float *, float *, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 size_t bm_tables_bytes(int stream) { return stream == 2 ? (1056 * 4 + 256 * 2) * 4 : (512 * 4 + 2048 * 2) * 4; }
 }  // namespace smmc
+
+// csrc/smmc_vector_add.hip (a whole C-ABI entry lives in that HIP file)
+extern "C" int smmc_vector_add(float *, const float *, const float *, int64_t, double *) { return SMMC_ERR_NO_DEVICE; }
