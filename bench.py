@@ -60,13 +60,21 @@ VALU_CHECK_PER_STEP = {"gaussian": 2 / 4, "table": 2 / 8}  # the range-checked d
 # step of the 397-step seed run-up, per output below output 227 and per output from 227 on (same ISA test)
 REF_VALU = {"runup_step": 24 / 8, "output_lo": 100 / 4, "output_hi": 128 / 4}
 REF_WINDOW = (397, 227, 454)  # run-up steps, first output of the second stretch, longest path of the windowed kernel
+# ref_tree_kernel (paths of 455 .. 1077 periods): first output of each stretch and the VALU instructions of its
+# written-out 4-output loop (tests/test_measurement_cpu.py re-derives them from the built kernel)
+REF_TREE_STRETCHES = ((0, 100 / 4), (227, 128 / 4), (454, 160 / 4), (623, 192 / 4), (681, 220 / 4), (850, 280 / 4), (908, 312 / 4))
+REF_TREE_MAX = 1077
+REF_CHECK_VALU = 4  # checked divide (kDivChecked): every 8 periods two float compares, a select and the flag's v_cmp
 
 
 def ref_valu_per_path(periods):
-    """VALU instructions ref_windowed_kernel spends on one path of `periods` <= 454 periods."""
-    runup, split, _ = REF_WINDOW
-    return (runup * REF_VALU["runup_step"] + min(periods, split) * REF_VALU["output_lo"]
-            + max(periods - split, 0) * REF_VALU["output_hi"])
+    """VALU instructions the state-free reference-stream kernels spend on one path: ref_windowed_kernel
+    (periods <= 454) or ref_tree_kernel (<= 1077), the same counts where both apply."""
+    total = REF_WINDOW[0] * REF_VALU["runup_step"]
+    starts = [t for t, _ in REF_TREE_STRETCHES] + [REF_TREE_MAX]
+    for (first, per_output), nxt in zip(REF_TREE_STRETCHES, starts[1:]):
+        total += max(min(periods, nxt) - first, 0) * per_output
+    return total
 # HBM bytes per launch measured by the round's rocprofv3 PMC passes (tools/pmc_traffic.py writes it)
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
@@ -255,7 +263,7 @@ def pmc_traffic(mode, n, periods, outputs):
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import isa_loop_count as I
-        if rec.get("source_sha256") != I.source_digest(mode):
+        if rec.get("source_sha256") != I.source_digest(I.traffic_kernel_of(f"{mode}|{n}|{periods}|{outputs}")):
             return None, f"stale: the kernel sources changed since {rec.get('source')}"
     except Exception as ex:
         return None, f"unverified: {ex}"
@@ -571,10 +579,13 @@ def main():
         kind = eng.divide_kind(sim)
         kernel_name = "paths_kernel"
         if args.stream == "ref":
-            windowed = periods <= REF_WINDOW[2]
-            kernel_name = "ref_windowed_kernel" if windowed else "ref_generic_kernel"
-            # the generic kernel (longer paths) keeps its generator states in memory and is not priced here
-            insts = ref_valu_per_path(periods) / periods if (windowed and kind == 0 and periods) else None
+            windowed = periods <= REF_TREE_MAX
+            kernel_name = ("ref_windowed_kernel" if periods <= REF_WINDOW[2] else
+                           "ref_tree_kernel" if windowed else "ref_generic_kernel")
+            # the generic kernel (longer paths still) keeps its generator states in memory and is not priced here
+            insts = None
+            if windowed and periods and kind in (0, 2):  # fast / checked; the IEEE divide is not counted
+                insts = ref_valu_per_path(periods) / periods + (REF_CHECK_VALU / 8 if kind == 2 else 0.0)
         elif args.stream == "2":
             insts = None  # round 1's stream: counts in DESIGN.md section 5, not tracked by the ISA test
         elif kind == 2:  # checked

@@ -144,7 +144,7 @@ struct smmc_engine {
   uint64_t ref_redo_cap = 0;
   uint32_t *d_ref_ws = nullptr;     // the generic kernel's generator states
   uint32_t ref_ws_grid = 0;
-  int ref_kernel = 0;               // SMMC_REF_KERNEL: 0 auto, 1 windowed (where it can), 2 generic
+  int ref_kernel = 0;               // SMMC_REF_KERNEL: 0 auto (also "tree", read by the launcher), 1 windowed (where it can), 2 generic
   // SMMC_REF_GENERIC_BLOCKS_PER_CU.  2e7 x 1000 paths (profiles/r03/ref_generic_sweep.txt): 1 per CU 85.8 ms, 2 60.0,
   // 4 48.3, 8 35.0 -- the chains that now supply the seed words want the occupancy; the 1.3 GB of generator
   // states no longer fit the Infinity Cache, but a path moves 41 % fewer bytes than when its seed words were stored
@@ -336,10 +336,11 @@ int values_stats_enqueue(smmc_engine *e, const float *d_values, uint64_t n, floa
 }
 
 // SMMC_FLAG_STREAM_REF: the reference's own stream (smmc_ref_kernels.hip).  Launches of at most 2^27 paths:
-// the windowed kernel where a path's outputs fit its window (n_periods <= 454), then a small generic
-// launch over the paths it left (a rejected generator output -- 1e-4 of the paths with the 1127-entry
-// table at 360 periods -- or a path that left the checked divide's window); the generic kernel for
-// everything when n_periods is larger.
+// a state-free kernel where it can generate a path's outputs (launch_ref_windowed: the windowed kernel up to
+// 454 periods, the tree kernel up to ref_windowed_max_outputs() = 1077; SMMC_REF_KERNEL=tree: the tree kernel
+// for both), then a small generic launch over the paths it left (a rejected generator output -- 1e-4 of the
+// paths with the 1127-entry table at 360 periods -- or a path that left the checked divide's window); the
+// generic kernel for everything when n_periods is larger.
 // Statistics and chunk outputs are second passes over the final values.  Device must be current.
 constexpr uint64_t kRefLaunchPaths = 1ull << 27;
 constexpr uint32_t kRefRedoGrid = 64;

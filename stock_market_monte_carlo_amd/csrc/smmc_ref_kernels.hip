@@ -20,6 +20,9 @@
 //     227 <= j < 454 need x[624 + (j - 227)], an earlier OUTPUT: it is generated again from two more
 //     seed chains (at j - 227 and j + 170) rather than kept -- three chain steps per output, still
 //     nothing stored, 30-odd VGPRs, full occupancy.
+//   ref_tree_kernel (455 .. 1077 outputs: BASELINE configs[4]'s 1000 periods): the same idea carried on as the
+//     recursion it is -- every operand that stops being a seed word is generated again from seed chains of its
+//     own, up to nine chains and eight twists per output, still nothing stored (see the section below).
 //   ref_generic_kernel (any length): the classic circular 624-word state, held in a global-memory
 //     workspace laid out [word][lane] so that every access of a wave is one coalesced 256-byte
 //     line -- but only for GENERATED words: the seed words still come from chains (two below output
@@ -31,11 +34,14 @@
 // Rejections (T / 2^32 per draw: 2.6e-7 for the 1127-entry table) shift a path's later draws by one
 // output.  Generation stays wave-uniform -- every lane generates output j at step j.  In the generic
 // kernel a lane that rejected simply does not compound at that step and goes on past output P; the
-// windowed kernel only flags it: the path goes on the redo list that a small generic launch works
+// windowed and tree kernels only flag it: the path goes on the redo list that a small generic launch works
 // off (so does a path that leaves the checked divide's window).
 //
 // Bound: VALU issue, like paths_kernel (DESIGN.md section 5 has the counts).  HBM sees 4 B per path.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
 
 #include "smmc_device.h"
 #include "smmc_internal.h"
@@ -261,6 +267,198 @@ __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
   }
 }
 
+// ---- the windowed recurrence carried on: outputs 454 .. 1076 (ref_tree_kernel) -------------------------------
+//
+// Output n is temper(new[n]),  new[k] = word(k + 397) ^ tw(word(k), word(k + 1)),  word(j) = x[j] for j < 624 (a
+// seed word: a chain) and new[j - 624] from there on.  The windowed kernel above is the first two stretches of
+// that recursion written out by hand: new[n] from three seed chains, then (n >= 227) with word(n + 397) itself
+// a new[], generated again from its own seed chains.  Written as the recursion it is, the same idea goes on:
+// at output 454 word(n + 397)'s own far operand becomes a new[], at 623 word(n + 1) does, and so on -- every
+// operand that stops being a seed word is replaced by a node that generates it from seed chains again, and
+// nothing is ever stored.  The tree of nodes is fixed at compile time for outputs below kTreeMax:
+//
+//   NewNode<O>   yields new[n + O] at output n;  holds the half of word(n + O) and two WordNodes
+//   WordNode<W>  yields word(n + W):  a seed chain while n + W < 624, then its NewNode<W - 624>
+//
+// Which operand is what changes only at the outputs 624 - W of the tree's WordNodes (227, 454, 623, 681, 850, 908
+// below 1077): between two of them the loop body is one fixed expression -- run_stretch<T> is instantiated per
+// stretch, `if constexpr` picks every node's form from T -- and at a stretch's first output the nodes that begin
+// there are started from x[0], x[1] and x[397] (every chain of the tree begins at index 1 or 397, whatever its
+// node's place).  Per output: 3 VALU per live chain, 4 per twist plus one XOR per two nested twists, 14 for
+// tempering, the Lemire product, the rejection flag and the step: 25 / 32 / 40 / 48 / 55 / 70 / 78 in the seven
+// stretches as compiled, 44 per period for a 1000-period path where the generic kernel's state traffic costs the time of
+// about 88.
+constexpr int kTreeMax = 1077;  // the next stretch (1077 ..) would add six more chains
+
+template <int kO, bool kExists = (-kO < kTreeMax)>
+struct NewNode {};
+template <int kW>
+struct WordNode {
+  uint32_t x;                      // seed form: x[n + kW]
+  NewNode<kW - int(kMtN)> gen;     // generated form (n + kW >= 624)
+};
+template <int kO>
+struct NewNode<kO, true> {
+  uint32_t ah;                     // word(n + kO) >> 1
+  WordNode<kO + 1> wa;             // word(n + kO + 1)
+  WordNode<kO + int(kMtM)> wc;     // word(n + kO + 397)
+};
+
+struct TreeSeeds {
+  uint32_t seed, x1, x397, k;  // x[0], x[1], x[397], mt_multiplier()
+};
+
+// the smallest switch output 624 - W above T among the tree's WordNodes (kTreeMax if none)
+constexpr int tree_next_word(int w, int t, int best);
+constexpr int tree_next_new(int o, int t, int best) {
+  if (-o >= kTreeMax) return best;
+  best = tree_next_word(o + 1, t, best);
+  return tree_next_word(o + int(kMtM), t, best);
+}
+constexpr int tree_next_word(int w, int t, int best) {
+  const int sw = int(kMtN) - w;
+  if (sw > t && sw < best) best = sw;
+  return tree_next_new(w - int(kMtN), t, best);
+}
+constexpr int tree_next_stretch(int t) { return tree_next_new(0, t, kTreeMax); }
+static_assert(tree_next_stretch(0) == 227 && tree_next_stretch(227) == 454 && tree_next_stretch(454) == 623 &&
+                  tree_next_stretch(623) == 681 && tree_next_stretch(681) == 850 && tree_next_stretch(850) == 908 &&
+                  tree_next_stretch(908) == kTreeMax,
+              "stretches of the reference-stream tree");
+
+// new[] values travel as p ^ q where that saves the XOR: a consumer that adds its own twist term folds all three
+// in one v_bitop3 (xor3).  Whether q is live is a compile-time property of the node in the stretch.
+struct TreeValue {
+  uint32_t p, q;
+};
+template <int kT, int kO>
+constexpr bool tree_new_is_pair() {
+  if constexpr (kT + kO + int(kMtM) < int(kMtN)) return true;  // far operand a seed word: (seed word, twist term)
+  else return !tree_new_is_pair<kT, kO + int(kMtM) - int(kMtN)>();
+}
+
+template <int kT, int kO>
+__device__ __forceinline__ TreeValue tree_pull_new(NewNode<kO, true> &s, uint32_t n, const TreeSeeds &sd);
+
+template <int kT, int kW>
+__device__ __forceinline__ uint32_t tree_pull_word(WordNode<kW> &w, uint32_t n, const TreeSeeds &sd) {
+  if constexpr (kT + kW < int(kMtN)) {
+    const uint32_t r = w.x;
+    w.x = mt_seed_step(w.x, n + static_cast<uint32_t>(kW + 1), sd.k);
+    return r;
+  } else {
+    const TreeValue v = tree_pull_new<kT, kW - int(kMtN)>(w.gen, n, sd);
+    if constexpr (tree_new_is_pair<kT, kW - int(kMtN)>()) return v.p ^ v.q;
+    else return v.p;
+  }
+}
+
+template <int kT, int kO>
+__device__ __forceinline__ TreeValue tree_pull_new(NewNode<kO, true> &s, uint32_t n, const TreeSeeds &sd) {
+  const uint32_t a1 = tree_pull_word<kT, kO + 1>(s.wa, n, sd);
+  const uint32_t a1h = a1 >> 1;
+  const uint32_t term = mt_twist_term(s.ah, a1h, a1);
+  s.ah = a1h;
+  if constexpr (kT + kO + int(kMtM) < int(kMtN)) {
+    return TreeValue{tree_pull_word<kT, kO + int(kMtM)>(s.wc, n, sd), term};
+  } else {
+    const TreeValue c = tree_pull_new<kT, kO + int(kMtM) - int(kMtN)>(s.wc.gen, n, sd);
+    if constexpr (tree_new_is_pair<kT, kO + int(kMtM) - int(kMtN)>()) return TreeValue{xor3(c.p, c.q, term), 0u};
+    else return TreeValue{c.p, term};
+  }
+}
+
+// the nodes whose first output is kT: new[0] needs word(0) >> 1, and its chains at x[1] and x[397]
+template <int kT, int kW>
+__device__ __forceinline__ void tree_begin_word(WordNode<kW> &w, const TreeSeeds &sd);
+template <int kT, int kO>
+__device__ __forceinline__ void tree_begin_new(NewNode<kO, true> &s, const TreeSeeds &sd) {
+  if constexpr (-kO == kT) {
+    s.ah = sd.seed >> 1;
+    s.wa.x = sd.x1;
+    s.wc.x = sd.x397;
+  } else if constexpr (-kO < kT) {
+    tree_begin_word<kT, kO + 1>(s.wa, sd);
+    tree_begin_word<kT, kO + int(kMtM)>(s.wc, sd);
+  }
+}
+template <int kT, int kW>
+__device__ __forceinline__ void tree_begin_word(WordNode<kW> &w, const TreeSeeds &sd) {
+  if constexpr (kT + kW >= int(kMtN) && -(kW - int(kMtN)) < kTreeMax) tree_begin_new<kT, kW - int(kMtN)>(w.gen, sd);
+}
+
+// outputs [kT, min(P, next stretch)), then the stretches after it
+template <int kT, typename Period>
+__device__ __forceinline__ void tree_run_stretch(NewNode<0, true> &top, const TreeSeeds &sd, uint32_t P, Period &period) {
+  if (P <= static_cast<uint32_t>(kT)) return;
+  constexpr int kNext = tree_next_stretch(kT);
+  tree_begin_new<kT, 0>(top, sd);
+  const uint32_t end = P < static_cast<uint32_t>(kNext) ? P : static_cast<uint32_t>(kNext);
+  auto output = [&](uint32_t n) {
+    const TreeValue v = tree_pull_new<kT, 0>(top, n, sd);
+    if constexpr (tree_new_is_pair<kT, 0>()) return v.p ^ v.q;
+    else return v.p;
+  };
+  uint32_t j = static_cast<uint32_t>(kT);
+  for (; j + 4u <= end; j += 4u) {  // four outputs per trip, written out (a loop holding a ballot is not unrolled with a remainder)
+#pragma unroll
+    for (uint32_t t = 0; t < 4u; ++t) period(output(j + t), j + t);
+  }
+  for (; j < end; ++j) period(output(j), j);
+  if constexpr (kNext < kTreeMax) tree_run_stretch<kNext>(top, sd, P, period);
+}
+
+// As ref_windowed_kernel (rejections and checked-divide leavers flagged for the redo launch, kTraj through the
+// wave's LDS tile), for paths of up to kTreeMax outputs.
+template <int kDiv, bool kTraj>
+__global__ __launch_bounds__(kBlock) void ref_tree_kernel(const RefArgs k) {
+  extern __shared__ __align__(16) float lds_table[];
+  for (uint32_t i = threadIdx.x; i < k.table_len; i += kBlock) lds_table[i] = k.table_a[i];
+  __syncthreads();
+  float *const tile = lds_table + ((k.table_len + 3u) & ~3u) + (threadIdx.x >> 6) * kTrajTileWords;  // kTraj only
+  constexpr bool kExactDiv = kDiv == kDivExact;
+  TreeSeeds sd;
+  sd.k = mt_multiplier();
+  const uint32_t P = k.n_periods;  // <= kTreeMax
+  const uint32_t n_chunks = (k.n_paths + kBlock - 1u) / kBlock;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t i = chunk * kBlock + threadIdx.x;
+    sd.seed = k.seed0 + i;
+    sd.x1 = mt_seed_step(sd.seed, 1u, sd.k);
+    sd.x397 = mt_run_up(sd.seed, sd.k);
+    NewNode<0, true> top;
+    float total = k.initial_capital;
+    uint64_t redo_mask = 0;
+    auto period = [&](uint32_t g, uint32_t j) {
+      const uint32_t y = mt_temper(g);
+      const uint64_t prod = static_cast<uint64_t>(y) * k.table_len;
+      redo_mask |= __ballot(static_cast<uint32_t>(prod) < k.reject_below);
+      total = compound<kExactDiv>(total, lds_table[static_cast<uint32_t>(prod >> 32)]);
+      if constexpr (kDiv == kDivChecked) {
+        if ((j & 7u) == 7u) redo_mask |= __ballot(!(total > k.chk_lo && total < k.chk_hi));
+      }
+      if constexpr (kTraj) {
+        tile[(threadIdx.x & 63u) * kTrajTileStride + (j & 31u)] = total;
+        if ((j & 31u) == 31u) traj_tile_flush(k, tile, chunk * kBlock + (threadIdx.x & ~63u), j - 30u, 32u);
+      }
+    };
+    if constexpr (kTraj) {
+      if (i < k.n_paths) k.d_traj[static_cast<size_t>(i) * (P + 1u)] = total;
+    }
+    tree_run_stretch<0>(top, sd, P, period);
+    if constexpr (kTraj) {
+      if (P & 31u) traj_tile_flush(k, tile, chunk * kBlock + (threadIdx.x & ~63u), (P & ~31u) + 1u, P & 31u);
+    }
+    if (i < k.n_paths) {
+      if ((redo_mask >> (threadIdx.x & 63u)) & 1u) {
+        k.redo_list[atomicAdd(k.redo_count, 1u)] = i;
+      } else {
+        k.d_final[i] = total;
+      }
+    }
+  }
+}
+
 // Any number of periods: the circular state in global memory, word s of lane l at workspace[s * L + l]
 // (L = lanes of the launch).  Work items are the paths 0 .. n_paths - 1, or -- redo_list given -- the
 // *redo_count paths the windowed kernel left over.
@@ -395,7 +593,9 @@ __global__ __launch_bounds__(kBlock) void chunk_stats_kernel(const float *values
 
 }  // namespace
 
-uint32_t ref_windowed_max_outputs() { return kMtN - 170u; }  // 454: outputs the windowed kernel can generate
+// outputs the state-free kernels can generate: ref_windowed_kernel up to 454, ref_tree_kernel from there to kTreeMax
+constexpr uint32_t kWindowedMax = kMtN - 170u;
+uint32_t ref_windowed_max_outputs() { return static_cast<uint32_t>(kTreeMax); }
 size_t ref_workspace_bytes(uint32_t grid) { return static_cast<size_t>(grid) * kBlock * kMtN * sizeof(uint32_t); }
 
 size_t ref_windowed_lds_bytes(uint32_t table_len, bool traj) {
@@ -419,6 +619,22 @@ hipError_t launch_ref(Kernel kernel, const RefArgs &a, uint32_t grid, size_t lds
 hipError_t launch_ref_windowed(const RefArgs &a, int div, uint32_t grid, hipStream_t stream) {
   const bool traj = a.d_traj != nullptr;
   const size_t lds = ref_windowed_lds_bytes(a.table_len, traj);
+  // SMMC_REF_KERNEL=tree (test / measurement knob): the tree form also for the lengths the hand-written one takes
+  const char *env = std::getenv("SMMC_REF_KERNEL");
+  const bool tree_always = env && !std::strcmp(env, "tree");
+  if (a.n_periods > kWindowedMax || tree_always) {
+    switch (div) {
+      case SMMC_DIV_FAST:
+        return traj ? launch_ref(ref_tree_kernel<kDivFast, true>, a, grid, lds, stream)
+                    : launch_ref(ref_tree_kernel<kDivFast, false>, a, grid, lds, stream);
+      case SMMC_DIV_CHECKED:
+        return traj ? launch_ref(ref_tree_kernel<kDivChecked, true>, a, grid, lds, stream)
+                    : launch_ref(ref_tree_kernel<kDivChecked, false>, a, grid, lds, stream);
+      default:
+        return traj ? launch_ref(ref_tree_kernel<kDivExact, true>, a, grid, lds, stream)
+                    : launch_ref(ref_tree_kernel<kDivExact, false>, a, grid, lds, stream);
+    }
+  }
   switch (div) {
     case SMMC_DIV_FAST:
       return traj ? launch_ref(ref_windowed_kernel<kDivFast, true>, a, grid, lds, stream)

@@ -101,9 +101,13 @@ def test_baseline_config0_size_matches_oracle_engine_r(eng, oracle, table):
     assert np.array_equal(st2.hist, st.hist) and st2.below == st.below and st2.sum == st.sum
 
 
-# 226/227/228: the windowed kernel's second stretch begins at output 227; 454 is the last length it takes,
-# from 455 on the generic kernel runs; 624/625: the state wraps
-@pytest.mark.parametrize("p", [0, 1, 2, 7, 8, 9, 226, 227, 228, 229, 360, 437, 438, 439, 453, 454, 455, 623, 624, 625, 1000, 1300])
+# 226/227/228: the windowed kernel's second stretch begins at output 227; 454 is the last length it takes; from 455 to
+# 1077 the tree kernel carries the recurrence on (its stretches begin at outputs 454, 623, 681, 850 and 908: lengths on
+# both sides of each, and lengths that leave one, two or three outputs to the remainder loop); from 1078 on the generic
+# kernel runs (624/625: its state wraps; 1248: twice)
+@pytest.mark.parametrize("p", [0, 1, 2, 7, 8, 9, 226, 227, 228, 229, 360, 437, 438, 439, 453, 454, 455, 456, 457, 458, 622, 623,
+                               624, 625, 626, 680, 681, 682, 683, 849, 850, 851, 852, 907, 908, 909, 910, 911, 1000, 1075, 1076,
+                               1077, 1078, 1079, 1248, 1300])
 def test_every_length_both_kernels(eng, oracle, table, p):
     n, seed0 = 2000 + 77, 2 ** 32 - 1000  # ragged; the seeds seed0 + id wrap past 2^32 inside the launch (path 1000 has seed 0)
     want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
@@ -112,12 +116,14 @@ def test_every_length_both_kernels(eng, oracle, table, p):
     assert np.array_equal(_bits(r.final.cpu().numpy()), _bits(want))
 
 
-@pytest.mark.parametrize("kernel", ["windowed", "generic"])
+@pytest.mark.parametrize("kernel", ["windowed", "tree", "generic"])
 @pytest.mark.parametrize("exact_div", [False, True])
 def test_forced_kernels_and_divides_agree(table, oracle, monkeypatch, kernel, exact_div):
+    """SMMC_REF_KERNEL: "tree" runs ref_tree_kernel also for the lengths ref_windowed_kernel takes by default (its
+    first two stretches are the same recurrence), "generic" the state-in-memory kernel for every length."""
     e = _engine(table, monkeypatch, SMMC_REF_KERNEL=kernel)
     try:
-        for p in (5, 300, 360):
+        for p in (5, 300, 360, 700):
             n, seed0 = 30011, 99
             want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
             r = e.simulate(_sim(n, p, seed0, exact_div=exact_div))
@@ -138,7 +144,7 @@ def test_rejections_take_the_redo_path(table, oracle, monkeypatch):
     want, _ = oracle.ref_mc_simulations(n, p, 1000.0, big, seed0)
     expect_rejecting = n * (1.0 - (1.0 - threshold / 2.0 ** 32) ** p)  # paths with at least one rejected output
     assert 50 < expect_rejecting < 5000
-    for kernel in ("auto", "windowed", "generic"):
+    for kernel in ("auto", "windowed", "tree", "generic"):
         e = _engine(big, monkeypatch, SMMC_REF_KERNEL=kernel)
         try:
             r = e.simulate(_sim(n, p, seed0))
@@ -146,6 +152,16 @@ def test_rejections_take_the_redo_path(table, oracle, monkeypatch):
             assert np.array_equal(_bits(r.final.cpu().numpy()), _bits(want)), kernel
         finally:
             e.close()
+    # the tree kernel's own lengths: 1000 periods, where one path in 350 rejects an output somewhere
+    n2, p2 = 100_000, 1000
+    want2, _ = oracle.ref_mc_simulations(n2, p2, 1000.0, big, seed0)
+    e = _engine(big, monkeypatch, SMMC_REF_KERNEL="auto")
+    try:
+        r = e.simulate(_sim(n2, p2, seed0))
+        e.sync()
+        assert np.array_equal(_bits(r.final.cpu().numpy()), _bits(want2))
+    finally:
+        e.close()
 
 
 def test_checked_divide_window_and_overflowing_paths(table, oracle, monkeypatch):
@@ -157,14 +173,14 @@ def test_checked_divide_window_and_overflowing_paths(table, oracle, monkeypatch)
     t[::10] = 60.0
     e = _engine(t, monkeypatch)
     try:
-        for cap in (1000.0, 1e30):
-            sim = _sim(20011, 400, 7, cap=cap)
+        for cap, p in ((1000.0, 400), (1e30, 700), (1e30, 400)):  # 700 periods: the tree kernel's checked variant (all overflow)
+            sim = _sim(20011, p, 7, cap=cap)
             assert e.divide_kind(sim) == DIV_CHECKED
-            want, _ = oracle.ref_mc_simulations(20011, 400, cap, t, 7)
+            want, _ = oracle.ref_mc_simulations(20011, p, cap, t, 7)
             r = e.simulate(sim)
             e.sync()
             got = r.final.cpu().numpy()
-            assert np.array_equal(_bits(got), _bits(want)), cap
+            assert np.array_equal(_bits(got), _bits(want)), (cap, p)
         assert np.isinf(want).any() and np.isfinite(want).any()
     finally:
         e.close()
@@ -199,7 +215,7 @@ def test_argument_errors(eng):
     assert st.count == 0 and int(st.hist.sum()) == 0
 
 
-@pytest.mark.parametrize("p", [0, 1, 31, 32, 33, 64, 227, 360, 454, 455, 700])
+@pytest.mark.parametrize("p", [0, 1, 31, 32, 33, 64, 227, 360, 454, 455, 700, 1000, 1077, 1078])
 def test_trajectories_of_the_reference_stream(eng, oracle, table, p):
     """mc_simulations_keepdata draws like mc_simulations (src/simulations.cpp:175-186: a generator per path,
     sample_returns_historical, many_updates): with SMMC_FLAG_STREAM_REF every row is many_updates of the table

@@ -1,6 +1,7 @@
 """Times the reference-stream kernels (SMMC_FLAG_STREAM_REF, smmc_ref_kernels.hip) with HIP events on the
-engine's stream: the windowed kernel at 360 periods, the generic kernel at 1000, beside the default
-Philox table stream on the same shapes.  One JSON line per case.
+engine's stream: the windowed kernel at 360 periods (and the tree kernel forced onto the same shape), the tree
+kernel at 700 and 1000 periods beside the generic kernel forced onto them, the generic kernel at 1300, and the
+default Philox table stream on the same shapes.  One JSON line per case.
 
 usage: bench_ref.py [n_paths_360] [n_paths_1000]
 """
@@ -20,10 +21,15 @@ def main():
     n360 = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
     n1000 = int(float(sys.argv[2])) if len(sys.argv) > 2 else 20_000_000
     table = load_table()
-    eng = S.Engine(0)
-    eng.set_table(table)
-    for name, n, p, stream in (("ref windowed", n360, 360, "ref"), ("philox table", n360, 360, 3),
-                               ("ref generic", n1000, 1000, "ref"), ("philox table", n1000, 1000, 3)):
+    cases = (("ref windowed", n360, 360, "ref", "auto"), ("ref tree (forced)", n360, 360, "ref", "tree"),
+             ("philox table", n360, 360, 3, "auto"),
+             ("ref tree", n1000, 700, "ref", "auto"), ("ref generic (forced)", n1000, 700, "ref", "generic"),
+             ("ref tree", n1000, 1000, "ref", "auto"), ("ref generic (forced)", n1000, 1000, "ref", "generic"),
+             ("philox table", n1000, 1000, 3, "auto"), ("ref generic", n1000, 1300, "ref", "auto"))
+    for name, n, p, stream, knob in cases:
+        os.environ["SMMC_REF_KERNEL"] = knob  # read when an engine is created and (tree) at every launch
+        eng = S.Engine(0)
+        eng.set_table(table)
         sim = S.Engine.make_sim(n, p, S.MODE_TABLE, 1000, stream=stream)
         out = torch.empty(n, dtype=torch.float32, device=eng.tdevice)
         eng.simulate(sim, out=out)
@@ -34,11 +40,11 @@ def main():
             eng.simulate(sim, out=out)
         ms, k = eng.kernel_ms()
         eng.timing(False)
-        ms /= max(k, 1)
+        ms /= reps  # per simulate call: the windowed / tree launch, its redo launch and (generic) every sub-launch
         print(json.dumps({"case": name, "n_paths": n, "n_periods": p, "kernel_ms": ms, "paths_per_s": n / ms * 1e3,
                           "hbm_GBps_final_values": 4.0 * n / ms / 1e6, "divide": ("fast", "exact", "checked")[eng.divide_kind(sim)],
                           "mean": float(out.double().mean())}), flush=True)
-    eng.close()
+        eng.close()
 
 
 if __name__ == "__main__":

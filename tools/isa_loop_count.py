@@ -67,7 +67,16 @@ def fingerprint(path, variant, kernel="paths_kernel"):
 # what each workload key of profiles/pmc_traffic.json was measured on: (source file, kernel, template arguments)
 TRAFFIC_KERNELS = {"gaussian": ("smmc_kernels.hip", "paths_kernel", "ILi1ELi0ELb0E"),
                    "table": ("smmc_kernels.hip", "paths_kernel", "ILi0ELi0ELb1E"),
-                   "ref": ("smmc_ref_kernels.hip", "ref_windowed_kernel", "ILi0ELb0E")}
+                   "ref": ("smmc_ref_kernels.hip", "ref_windowed_kernel", "ILi0ELb0E"),
+                   # the bundled table over 1000 periods cannot be proven safe for the fast divide: the checked variant runs
+                   "ref_tree": ("smmc_ref_kernels.hip", "ref_tree_kernel", "ILi2ELb0E")}
+REF_WINDOWED_MAX = 454  # longer paths of the reference stream (up to 1077 periods) run ref_tree_kernel
+
+
+def traffic_kernel_of(key):
+    """TRAFFIC_KERNELS entry name for a workload key `mode|paths|periods|outputs` of profiles/pmc_traffic.json."""
+    mode, _, periods, _ = key.split("|")
+    return "ref_tree" if mode == "ref" and int(periods) > REF_WINDOWED_MAX else mode
 
 
 def source_digest(mode):

@@ -54,8 +54,11 @@ def main():
     ap.add_argument("--source", required=True)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     a = ap.parse_args()
-    mode = a.key.split("|")[0]
-    kernel = "ref_windowed_kernel" if mode == "ref" else "paths_kernel"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import isa_loop_count as I
+    mode = I.traffic_kernel_of(a.key)
+    kernel = I.TRAFFIC_KERNELS[mode][1]
     w, nw = mean_counter(a.write, "WRITE_SIZE", kernel)
     f, nf = mean_counter(a.fetch, "FETCH_SIZE", kernel)
     try:

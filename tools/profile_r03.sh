@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-3 profiling recipe (GPU box, from the repo root through gpurun).  Kernel-trace/stats and each
 # PMC group are separate rocprofv3 runs of the SAME command line bench.py is judged on: configs[1]
-# (Gaussian, the headline), configs[2] (table) and the reference CPU stream on the device (--stream ref).
+# (Gaussian, the headline), configs[2] (table) and the reference CPU stream on the device (--stream ref: 360
+# periods = ref_windowed_kernel, 1000 periods = ref_tree_kernel).
 # Writes gpurun_out/$PROF_TAG/{trace_*,pmc_*}, pmc_summary.txt and pmc_traffic.json (with the ISA
 # fingerprint and source digest of the build that was profiled); copy what is judged into profiles/r03/
 # and pmc_traffic.json to profiles/.
@@ -22,14 +23,16 @@ run_passes() {  # tag, bench arguments...
 run_passes c1 --config 1 || exit 1
 run_passes c2 --config 2 || exit 1
 run_passes ref --config 2 --stream ref --outputs final || exit 1
+run_passes ref1000 --config 2 --stream ref --outputs final --periods 1000 --paths-per-gpu 20000000 || exit 1
 cd $R
 python3 tools/pmc_summary.py $OUT/pmc_sq_c1 $OUT/pmc_wr_c1 $OUT/pmc_rd_c1 $OUT/pmc_sq_c2 $OUT/pmc_wr_c2 $OUT/pmc_rd_c2 \
-        $OUT/pmc_sq_ref $OUT/pmc_wr_ref $OUT/pmc_rd_ref > $OUT/pmc_summary.txt
+        $OUT/pmc_sq_ref $OUT/pmc_wr_ref $OUT/pmc_rd_ref $OUT/pmc_sq_ref1000 $OUT/pmc_wr_ref1000 $OUT/pmc_rd_ref1000 > $OUT/pmc_summary.txt
 SRC="profiles/r03/pmc_summary.txt (tools/profile_r03.sh)"
 python3 tools/pmc_traffic.py --key "gaussian|100000000|360|all" --write $OUT/pmc_wr_c1 --fetch $OUT/pmc_rd_c1 --source "$SRC" --out $OUT/pmc_traffic.json
 python3 tools/pmc_traffic.py --key "table|100000000|360|all" --write $OUT/pmc_wr_c2 --fetch $OUT/pmc_rd_c2 --source "$SRC" --out $OUT/pmc_traffic.json
 python3 tools/pmc_traffic.py --key "ref|100000000|360|final" --write $OUT/pmc_wr_ref --fetch $OUT/pmc_rd_ref --source "$SRC" --out $OUT/pmc_traffic.json
-for T in c1 c2 ref; do
+python3 tools/pmc_traffic.py --key "ref|20000000|1000|final" --write $OUT/pmc_wr_ref1000 --fetch $OUT/pmc_rd_ref1000 --source "$SRC" --out $OUT/pmc_traffic.json
+for T in c1 c2 ref ref1000; do
   F=$(find $OUT/trace_$T -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && cp $F $OUT/kernel_stats_$T.csv
   grep '^{"metric"' $OUT/trace_$T.log | tail -1 > $OUT/bench_under_rocprof_$T.json
