@@ -60,16 +60,18 @@ VALU_CHECK_PER_STEP = {"gaussian": 2 / 4, "table": 2 / 8}  # the range-checked d
 # step of the 397-step seed run-up, per output below output 227 and per output from 227 on (same ISA test)
 REF_VALU = {"runup_step": 24 / 8, "output_lo": 100 / 4, "output_hi": 128 / 4}
 REF_WINDOW = (397, 227, 454)  # run-up steps, first output of the second stretch, longest path of the windowed kernel
-# ref_tree_kernel (paths of 455 .. 1077 periods): first output of each stretch and the VALU instructions of its
+# ref_tree_kernel (paths of 455 .. 1816 periods): first output of each stretch and the VALU instructions of its
 # written-out 4-output loop (tests/test_measurement_cpu.py re-derives them from the built kernel)
-REF_TREE_STRETCHES = ((0, 100 / 4), (227, 128 / 4), (454, 160 / 4), (623, 192 / 4), (681, 220 / 4), (850, 280 / 4), (908, 312 / 4))
-REF_TREE_MAX = 1077
+REF_TREE_STRETCHES = ((0, 100 / 4), (227, 128 / 4), (454, 160 / 4), (623, 180 / 4), (681, 208 / 4), (850, 228 / 4), (908, 260 / 4),
+                      (1077, 280 / 4), (1135, 308 / 4), (1246, 328 / 4), (1304, 348 / 4), (1362, 380 / 4), (1473, 400 / 4),
+                      (1531, 420 / 4), (1589, 448 / 4), (1700, 468 / 4), (1758, 488 / 4))
+REF_TREE_MAX = 1816
 REF_CHECK_VALU = 4  # checked divide (kDivChecked): every 8 periods two float compares, a select and the flag's v_cmp
 
 
 def ref_valu_per_path(periods):
     """VALU instructions the state-free reference-stream kernels spend on one path: ref_windowed_kernel
-    (periods <= 454) or ref_tree_kernel (<= 1077), the same counts where both apply."""
+    (periods <= 454) or ref_tree_kernel (<= 1816), the same counts where both apply."""
     total = REF_WINDOW[0] * REF_VALU["runup_step"]
     starts = [t for t, _ in REF_TREE_STRETCHES] + [REF_TREE_MAX]
     for (first, per_output), nxt in zip(REF_TREE_STRETCHES, starts[1:]):

@@ -337,7 +337,7 @@ int values_stats_enqueue(smmc_engine *e, const float *d_values, uint64_t n, floa
 
 // SMMC_FLAG_STREAM_REF: the reference's own stream (smmc_ref_kernels.hip).  Launches of at most 2^27 paths:
 // a state-free kernel where it can generate a path's outputs (launch_ref_windowed: the windowed kernel up to
-// 454 periods, the tree kernel up to ref_windowed_max_outputs() = 1077; SMMC_REF_KERNEL=tree: the tree kernel
+// 454 periods, the tree kernel up to ref_windowed_max_outputs() = 1816; SMMC_REF_KERNEL=tree: the tree kernel
 // for both), then a small generic launch over the paths it left (a rejected generator output -- 1e-4 of the
 // paths with the 1127-entry table at 360 periods -- or a path that left the checked divide's window); the
 // generic kernel for everything when n_periods is larger.

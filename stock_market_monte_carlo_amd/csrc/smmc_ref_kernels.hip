@@ -20,9 +20,10 @@
 //     227 <= j < 454 need x[624 + (j - 227)], an earlier OUTPUT: it is generated again from two more
 //     seed chains (at j - 227 and j + 170) rather than kept -- three chain steps per output, still
 //     nothing stored, 30-odd VGPRs, full occupancy.
-//   ref_tree_kernel (455 .. 1077 outputs: BASELINE configs[4]'s 1000 periods): the same idea carried on as the
-//     recursion it is -- every operand that stops being a seed word is generated again from seed chains of its
-//     own, up to nine chains and eight twists per output, still nothing stored (see the section below).
+//   ref_tree_kernel (455 .. 1816 outputs: BASELINE configs[4]'s 1000 periods): the same idea carried on as the
+//     recursion it is -- every operand that stops being a seed word is generated again from seed chains, shared
+//     between the operands that walk the same words: six chains and seven made words per output at 1000 periods,
+//     nine and seventeen at 1816, still nothing stored (see the section below).
 //   ref_generic_kernel (any length): the classic circular 624-word state, held in a global-memory
 //     workspace laid out [word][lane] so that every access of a wave is one coalesced 256-byte
 //     line -- but only for GENERATED words: the seed words still come from chains (two below output
@@ -267,137 +268,188 @@ __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
   }
 }
 
-// ---- the windowed recurrence carried on: outputs 454 .. 1076 (ref_tree_kernel) -------------------------------
+// ---- the windowed recurrence carried on: paths of 455 .. 1816 outputs (ref_tree_kernel) -----------------------
 //
 // Output n is temper(new[n]),  new[k] = word(k + 397) ^ tw(word(k), word(k + 1)),  word(j) = x[j] for j < 624 (a
 // seed word: a chain) and new[j - 624] from there on.  The windowed kernel above is the first two stretches of
 // that recursion written out by hand: new[n] from three seed chains, then (n >= 227) with word(n + 397) itself
 // a new[], generated again from its own seed chains.  Written as the recursion it is, the same idea goes on:
 // at output 454 word(n + 397)'s own far operand becomes a new[], at 623 word(n + 1) does, and so on -- every
-// operand that stops being a seed word is replaced by a node that generates it from seed chains again, and
-// nothing is ever stored.  The tree of nodes is fixed at compile time for outputs below kTreeMax:
+// operand that stops being a seed word is generated again, from seed chains of its own, and nothing is ever
+// stored.  What a path carries is one word per STREAM:
 //
-//   NewNode<O>   yields new[n + O] at output n;  holds the half of word(n + O) and two WordNodes
-//   WordNode<W>  yields word(n + W):  a seed chain while n + W < 624, then its NewNode<W - 624>
+//   stream W  =  word(n + W) at output n:  the seed chain x[n + W] while n + W < 624 ("seed form"), afterwards
+//                new[n + W - 624], made from the streams W - 623 (its word(k + 1)) and W - 227 (its word(k + 397))
+//                and the half of its own previous word(k); the output itself is stream 624.
 //
-// Which operand is what changes only at the outputs 624 - W of the tree's WordNodes (227, 454, 623, 681, 850, 908
-// below 1077): between two of them the loop body is one fixed expression -- run_stretch<T> is instantiated per
-// stretch, `if constexpr` picks every node's form from T -- and at a stretch's first output the nodes that begin
-// there are started from x[0], x[1] and x[397] (every chain of the tree begins at index 1 or 397, whatever its
-// node's place).  Per output: 3 VALU per live chain, 4 per twist plus one XOR per two nested twists, 14 for
-// tempering, the Lemire product, the rejection flag and the step: 25 / 32 / 40 / 48 / 55 / 70 / 78 in the seven
-// stretches as compiled, 44 per period for a 1000-period path where the generic kernel's state traffic costs the time of
-// about 88.
-constexpr int kTreeMax = 1077;  // the next stretch (1077 ..) would add six more chains
+// Streams are shared: word(n - 453) is the far operand of one node and the near operand of another, and one
+// chain serves both (a tree that gave every operand its own chain would carry 9 chains and 8 twists per output
+// from output 908, 42 and 41 from output 1869; shared, 6 and 7, 10 and 19).  The set of streams, the output at
+// which each begins (its first user's first output: every chain begins at x[1] or x[397]) and the output 624 - W
+// at which it changes form are compile-time tables (tree_tables()); between two such outputs the loop body is one
+// fixed expression -- tree_run_stretch<S> is instantiated per stretch, `if constexpr` picks every stream's form,
+// evaluated in ascending W (a stream's operands have smaller W) -- and at a stretch's first output the streams that
+// begin or change form there are set up.  A made word travels as a pair p ^ q where that saves the XOR (a user
+// that adds its own twist term folds all three in one v_bitop3).  Per output: 3 VALU per live chain, 4-5 per
+// made word, 14 for tempering, the Lemire product, the rejection flag and the step.
+// Two instantiations: paths of up to 1077 periods carry 13 words of stream state (45 VGPRs, eight waves per SIMD),
+// paths of up to 1816 periods 26 (70 VGPRs, seven waves); longer ones go to ref_generic_kernel.
+constexpr int kTreeMaxShort = 1077, kTreeMaxLong = 1816;
+constexpr int kTreeCap = 64;     // room in the tables
 
-template <int kO, bool kExists = (-kO < kTreeMax)>
-struct NewNode {};
-template <int kW>
-struct WordNode {
-  uint32_t x;                      // seed form: x[n + kW]
-  NewNode<kW - int(kMtN)> gen;     // generated form (n + kW >= 624)
+struct TreeTables {
+  int n = 0;                 // streams, ascending W; the last one is W = 624, the output
+  int w[kTreeCap] = {};      // W
+  int first[kTreeCap] = {};  // the output at which the stream begins
+  int n_stretch = 0;
+  int stretch[kTreeCap] = {};  // first outputs of the stretches: 0 and every 624 - W inside (0, kTreeMax)
 };
-template <int kO>
-struct NewNode<kO, true> {
-  uint32_t ah;                     // word(n + kO) >> 1
-  WordNode<kO + 1> wa;             // word(n + kO + 1)
-  WordNode<kO + int(kMtM)> wc;     // word(n + kO + 397)
+
+constexpr TreeTables tree_tables(int kTreeMax) {
+  TreeTables t;
+  // worklist of streams: a stream W made (from output 624 - W on) needs the streams W - 623 and W - 227 from then on
+  int work_w[4 * kTreeCap] = {}, work_first[4 * kTreeCap] = {}, n_work = 0;
+  work_w[n_work] = int(kMtN);
+  work_first[n_work++] = 0;
+  for (int i = 0; i < n_work; ++i) {
+    const int w = work_w[i], first = work_first[i];
+    int at = -1;
+    for (int j = 0; j < t.n; ++j)
+      if (t.w[j] == w) at = j;
+    if (at >= 0) {  // known: its operands are on the list already (with the same outputs: 624 - W does not depend on the user)
+      if (first < t.first[at]) t.first[at] = first;
+      continue;
+    }
+    t.w[t.n] = w;
+    t.first[t.n++] = first;
+    const int made_from = int(kMtN) - w;  // the output at which this stream changes form
+    if (made_from < kTreeMax) {
+      const int from = made_from < 0 ? 0 : made_from;
+      work_w[n_work] = w - int(kMtN) + 1;
+      work_first[n_work++] = from;
+      work_w[n_work] = w - int(kMtLag);
+      work_first[n_work++] = from;
+    }
+  }
+  for (int i = 1; i < t.n; ++i)  // ascending W
+    for (int j = i; j > 0 && t.w[j - 1] > t.w[j]; --j) {
+      const int tw_ = t.w[j], tf = t.first[j];
+      t.w[j] = t.w[j - 1];
+      t.first[j] = t.first[j - 1];
+      t.w[j - 1] = tw_;
+      t.first[j - 1] = tf;
+    }
+  t.stretch[t.n_stretch++] = 0;
+  for (int pass = 0; pass < kTreeCap; ++pass) {  // the next larger 624 - W, until none is left
+    const int last = t.stretch[t.n_stretch - 1];
+    int best = kTreeMax;
+    for (int j = 0; j < t.n; ++j) {
+      const int sw = int(kMtN) - t.w[j];
+      if (sw > last && sw < best) best = sw;
+    }
+    if (best == kTreeMax) break;
+    t.stretch[t.n_stretch++] = best;
+  }
+  return t;
+}
+template <int kMax>
+struct Tree {
+  static constexpr TreeTables t = tree_tables(kMax);
+  static constexpr int index_of(int w) {
+    for (int j = 0; j < t.n; ++j)
+      if (t.w[j] == w) return j;
+    return -1;
+  }
+  static constexpr bool live(int out, int i) { return i >= 0 && t.first[i] <= out; }
+  static constexpr bool made(int out, int i) { return out + t.w[i] >= int(kMtN); }
+  // a made word is left as a pair exactly when its far operand is a single word
+  static constexpr bool is_pair(int out, int i) {
+    if (!made(out, i)) return false;
+    return !is_pair(out, index_of(t.w[i] - int(kMtLag)));
+  }
 };
+static_assert(Tree<kTreeMaxLong>::t.n < kTreeCap && Tree<kTreeMaxLong>::t.n_stretch < kTreeCap, "tree tables");
+static_assert(Tree<kTreeMaxShort>::t.w[Tree<kTreeMaxShort>::t.n - 1] == int(kMtN) && Tree<kTreeMaxShort>::t.n_stretch == 7 &&
+                  Tree<kTreeMaxLong>::t.n_stretch == 17 && Tree<kTreeMaxLong>::t.stretch[1] == 227 &&
+                  Tree<kTreeMaxLong>::t.stretch[2] == 454 && Tree<kTreeMaxLong>::t.stretch[3] == 623 &&
+                  Tree<kTreeMaxLong>::t.stretch[4] == 681 && Tree<kTreeMaxLong>::t.stretch[5] == 850 &&
+                  Tree<kTreeMaxLong>::t.stretch[6] == 908 && Tree<kTreeMaxLong>::t.stretch[7] == 1077,
+              "stretches of the reference-stream tree");
 
 struct TreeSeeds {
   uint32_t seed, x1, x397, k;  // x[0], x[1], x[397], mt_multiplier()
 };
-
-// the smallest switch output 624 - W above T among the tree's WordNodes (kTreeMax if none)
-constexpr int tree_next_word(int w, int t, int best);
-constexpr int tree_next_new(int o, int t, int best) {
-  if (-o >= kTreeMax) return best;
-  best = tree_next_word(o + 1, t, best);
-  return tree_next_word(o + int(kMtM), t, best);
-}
-constexpr int tree_next_word(int w, int t, int best) {
-  const int sw = int(kMtN) - w;
-  if (sw > t && sw < best) best = sw;
-  return tree_next_new(w - int(kMtN), t, best);
-}
-constexpr int tree_next_stretch(int t) { return tree_next_new(0, t, kTreeMax); }
-static_assert(tree_next_stretch(0) == 227 && tree_next_stretch(227) == 454 && tree_next_stretch(454) == 623 &&
-                  tree_next_stretch(623) == 681 && tree_next_stretch(681) == 850 && tree_next_stretch(850) == 908 &&
-                  tree_next_stretch(908) == kTreeMax,
-              "stretches of the reference-stream tree");
-
-// new[] values travel as p ^ q where that saves the XOR: a consumer that adds its own twist term folds all three
-// in one v_bitop3 (xor3).  Whether q is live is a compile-time property of the node in the stretch.
-struct TreeValue {
-  uint32_t p, q;
+struct TreeState {
+  uint32_t s[kTreeCap];  // per stream: the chain's word x[n + W] (seed form) or word(n + W - 624) >> 1 (made)
 };
-template <int kT, int kO>
-constexpr bool tree_new_is_pair() {
-  if constexpr (kT + kO + int(kMtM) < int(kMtN)) return true;  // far operand a seed word: (seed word, twist term)
-  else return !tree_new_is_pair<kT, kO + int(kMtM) - int(kMtN)>();
+struct TreeWords {
+  uint32_t p[kTreeCap], q[kTreeCap];  // this output's word of every live stream: p, or p ^ q
+};
+
+template <int kMax, int kT, int kI>
+__device__ __forceinline__ uint32_t tree_single(const TreeWords &v) {
+  if constexpr (Tree<kMax>::is_pair(kT, kI)) return v.p[kI] ^ v.q[kI];
+  else return v.p[kI];
 }
 
-template <int kT, int kO>
-__device__ __forceinline__ TreeValue tree_pull_new(NewNode<kO, true> &s, uint32_t n, const TreeSeeds &sd);
-
-template <int kT, int kW>
-__device__ __forceinline__ uint32_t tree_pull_word(WordNode<kW> &w, uint32_t n, const TreeSeeds &sd) {
-  if constexpr (kT + kW < int(kMtN)) {
-    const uint32_t r = w.x;
-    w.x = mt_seed_step(w.x, n + static_cast<uint32_t>(kW + 1), sd.k);
-    return r;
-  } else {
-    const TreeValue v = tree_pull_new<kT, kW - int(kMtN)>(w.gen, n, sd);
-    if constexpr (tree_new_is_pair<kT, kW - int(kMtN)>()) return v.p ^ v.q;
-    else return v.p;
+// streams kI, kI + 1, ... of output n in stretch kT
+template <int kMax, int kT, int kI>
+__device__ __forceinline__ void tree_eval(TreeState &st, TreeWords &v, uint32_t n, const TreeSeeds &sd) {
+  using Tr = Tree<kMax>;
+  if constexpr (kI < Tr::t.n) {
+    if constexpr (Tr::live(kT, kI)) {
+      constexpr int kW = Tr::t.w[kI];
+      if constexpr (!Tr::made(kT, kI)) {
+        v.p[kI] = st.s[kI];
+        st.s[kI] = mt_seed_step(st.s[kI], n + static_cast<uint32_t>(kW + 1), sd.k);
+      } else {
+        constexpr int kNear = Tr::index_of(kW - int(kMtN) + 1), kFar = Tr::index_of(kW - int(kMtLag));
+        static_assert(Tr::live(kT, kNear) && Tr::live(kT, kFar) && kNear < kI && kFar < kI, "operands come first");
+        const uint32_t a1 = tree_single<kMax, kT, kNear>(v);
+        const uint32_t a1h = a1 >> 1;
+        const uint32_t term = mt_twist_term(st.s[kI], a1h, a1);
+        st.s[kI] = a1h;
+        if constexpr (Tr::is_pair(kT, kFar)) {
+          v.p[kI] = xor3(v.p[kFar], v.q[kFar], term);
+        } else {
+          v.p[kI] = v.p[kFar];
+          v.q[kI] = term;
+        }
+      }
+    }
+    tree_eval<kMax, kT, kI + 1>(st, v, n, sd);
   }
 }
 
-template <int kT, int kO>
-__device__ __forceinline__ TreeValue tree_pull_new(NewNode<kO, true> &s, uint32_t n, const TreeSeeds &sd) {
-  const uint32_t a1 = tree_pull_word<kT, kO + 1>(s.wa, n, sd);
-  const uint32_t a1h = a1 >> 1;
-  const uint32_t term = mt_twist_term(s.ah, a1h, a1);
-  s.ah = a1h;
-  if constexpr (kT + kO + int(kMtM) < int(kMtN)) {
-    return TreeValue{tree_pull_word<kT, kO + int(kMtM)>(s.wc, n, sd), term};
-  } else {
-    const TreeValue c = tree_pull_new<kT, kO + int(kMtM) - int(kMtN)>(s.wc.gen, n, sd);
-    if constexpr (tree_new_is_pair<kT, kO + int(kMtM) - int(kMtN)>()) return TreeValue{xor3(c.p, c.q, term), 0u};
-    else return TreeValue{c.p, term};
+// the streams that begin at output kT (a chain at x[1] or x[397]) or change form there (word(0) >> 1)
+template <int kMax, int kT, int kI>
+__device__ __forceinline__ void tree_begin(TreeState &st, const TreeSeeds &sd) {
+  using Tr = Tree<kMax>;
+  if constexpr (kI < Tr::t.n) {
+    constexpr int kW = Tr::t.w[kI];
+    if constexpr (int(kMtN) - kW == kT || (kW >= int(kMtN) && kT == 0)) {
+      st.s[kI] = sd.seed >> 1;
+    } else if constexpr (Tr::t.first[kI] == kT) {
+      static_assert(kT + kW == 1 || kT + kW == int(kMtM), "a chain begins at x[1] or x[397]");
+      st.s[kI] = kT + kW == 1 ? sd.x1 : sd.x397;
+    }
+    tree_begin<kMax, kT, kI + 1>(st, sd);
   }
 }
 
-// the nodes whose first output is kT: new[0] needs word(0) >> 1, and its chains at x[1] and x[397]
-template <int kT, int kW>
-__device__ __forceinline__ void tree_begin_word(WordNode<kW> &w, const TreeSeeds &sd);
-template <int kT, int kO>
-__device__ __forceinline__ void tree_begin_new(NewNode<kO, true> &s, const TreeSeeds &sd) {
-  if constexpr (-kO == kT) {
-    s.ah = sd.seed >> 1;
-    s.wa.x = sd.x1;
-    s.wc.x = sd.x397;
-  } else if constexpr (-kO < kT) {
-    tree_begin_word<kT, kO + 1>(s.wa, sd);
-    tree_begin_word<kT, kO + int(kMtM)>(s.wc, sd);
-  }
-}
-template <int kT, int kW>
-__device__ __forceinline__ void tree_begin_word(WordNode<kW> &w, const TreeSeeds &sd) {
-  if constexpr (kT + kW >= int(kMtN) && -(kW - int(kMtN)) < kTreeMax) tree_begin_new<kT, kW - int(kMtN)>(w.gen, sd);
-}
-
-// outputs [kT, min(P, next stretch)), then the stretches after it
-template <int kT, typename Period>
-__device__ __forceinline__ void tree_run_stretch(NewNode<0, true> &top, const TreeSeeds &sd, uint32_t P, Period &period) {
+// outputs [stretch kS, min(P, stretch kS + 1)), then the stretches after it
+template <int kMax, int kS, typename Period>
+__device__ __forceinline__ void tree_run_stretch(TreeState &st, const TreeSeeds &sd, uint32_t P, Period &period) {
+  using Tr = Tree<kMax>;
+  constexpr int kT = Tr::t.stretch[kS];
   if (P <= static_cast<uint32_t>(kT)) return;
-  constexpr int kNext = tree_next_stretch(kT);
-  tree_begin_new<kT, 0>(top, sd);
+  constexpr int kNext = kS + 1 < Tr::t.n_stretch ? Tr::t.stretch[kS + 1] : kMax;
+  tree_begin<kMax, kT, 0>(st, sd);
   const uint32_t end = P < static_cast<uint32_t>(kNext) ? P : static_cast<uint32_t>(kNext);
   auto output = [&](uint32_t n) {
-    const TreeValue v = tree_pull_new<kT, 0>(top, n, sd);
-    if constexpr (tree_new_is_pair<kT, 0>()) return v.p ^ v.q;
-    else return v.p;
+    TreeWords v;
+    tree_eval<kMax, kT, 0>(st, v, n, sd);
+    return tree_single<kMax, kT, Tr::t.n - 1>(v);
   };
   uint32_t j = static_cast<uint32_t>(kT);
   for (; j + 4u <= end; j += 4u) {  // four outputs per trip, written out (a loop holding a ballot is not unrolled with a remainder)
@@ -405,12 +457,12 @@ __device__ __forceinline__ void tree_run_stretch(NewNode<0, true> &top, const Tr
     for (uint32_t t = 0; t < 4u; ++t) period(output(j + t), j + t);
   }
   for (; j < end; ++j) period(output(j), j);
-  if constexpr (kNext < kTreeMax) tree_run_stretch<kNext>(top, sd, P, period);
+  if constexpr (kS + 1 < Tr::t.n_stretch) tree_run_stretch<kMax, kS + 1>(st, sd, P, period);
 }
 
 // As ref_windowed_kernel (rejections and checked-divide leavers flagged for the redo launch, kTraj through the
-// wave's LDS tile), for paths of up to kTreeMax outputs.
-template <int kDiv, bool kTraj>
+// wave's LDS tile), for paths of up to kMax outputs.
+template <int kDiv, bool kTraj, int kMax>
 __global__ __launch_bounds__(kBlock) void ref_tree_kernel(const RefArgs k) {
   extern __shared__ __align__(16) float lds_table[];
   for (uint32_t i = threadIdx.x; i < k.table_len; i += kBlock) lds_table[i] = k.table_a[i];
@@ -419,14 +471,14 @@ __global__ __launch_bounds__(kBlock) void ref_tree_kernel(const RefArgs k) {
   constexpr bool kExactDiv = kDiv == kDivExact;
   TreeSeeds sd;
   sd.k = mt_multiplier();
-  const uint32_t P = k.n_periods;  // <= kTreeMax
+  const uint32_t P = k.n_periods;  // <= kMax
   const uint32_t n_chunks = (k.n_paths + kBlock - 1u) / kBlock;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t i = chunk * kBlock + threadIdx.x;
     sd.seed = k.seed0 + i;
     sd.x1 = mt_seed_step(sd.seed, 1u, sd.k);
     sd.x397 = mt_run_up(sd.seed, sd.k);
-    NewNode<0, true> top;
+    TreeState st;
     float total = k.initial_capital;
     uint64_t redo_mask = 0;
     auto period = [&](uint32_t g, uint32_t j) {
@@ -445,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void ref_tree_kernel(const RefArgs k) {
     if constexpr (kTraj) {
       if (i < k.n_paths) k.d_traj[static_cast<size_t>(i) * (P + 1u)] = total;
     }
-    tree_run_stretch<0>(top, sd, P, period);
+    tree_run_stretch<kMax, 0>(st, sd, P, period);
     if constexpr (kTraj) {
       if (P & 31u) traj_tile_flush(k, tile, chunk * kBlock + (threadIdx.x & ~63u), (P & ~31u) + 1u, P & 31u);
     }
@@ -593,9 +645,9 @@ __global__ __launch_bounds__(kBlock) void chunk_stats_kernel(const float *values
 
 }  // namespace
 
-// outputs the state-free kernels can generate: ref_windowed_kernel up to 454, ref_tree_kernel from there to kTreeMax
+// outputs the state-free kernels can generate: ref_windowed_kernel up to 454, ref_tree_kernel from there to kTreeMaxLong
 constexpr uint32_t kWindowedMax = kMtN - 170u;
-uint32_t ref_windowed_max_outputs() { return static_cast<uint32_t>(kTreeMax); }
+uint32_t ref_windowed_max_outputs() { return static_cast<uint32_t>(kTreeMaxLong); }
 size_t ref_workspace_bytes(uint32_t grid) { return static_cast<size_t>(grid) * kBlock * kMtN * sizeof(uint32_t); }
 
 size_t ref_windowed_lds_bytes(uint32_t table_len, bool traj) {
@@ -615,6 +667,23 @@ hipError_t launch_ref(Kernel kernel, const RefArgs &a, uint32_t grid, size_t lds
 }
 }  // namespace
 
+namespace {
+template <int kMax>
+hipError_t launch_ref_tree(const RefArgs &a, int div, bool traj, uint32_t grid, size_t lds, hipStream_t stream) {
+  switch (div) {
+    case SMMC_DIV_FAST:
+      return traj ? launch_ref(ref_tree_kernel<kDivFast, true, kMax>, a, grid, lds, stream)
+                  : launch_ref(ref_tree_kernel<kDivFast, false, kMax>, a, grid, lds, stream);
+    case SMMC_DIV_CHECKED:
+      return traj ? launch_ref(ref_tree_kernel<kDivChecked, true, kMax>, a, grid, lds, stream)
+                  : launch_ref(ref_tree_kernel<kDivChecked, false, kMax>, a, grid, lds, stream);
+    default:
+      return traj ? launch_ref(ref_tree_kernel<kDivExact, true, kMax>, a, grid, lds, stream)
+                  : launch_ref(ref_tree_kernel<kDivExact, false, kMax>, a, grid, lds, stream);
+  }
+}
+}  // namespace
+
 // a.d_traj != nullptr: every value of every path as well (rows of n_periods + 1 floats)
 hipError_t launch_ref_windowed(const RefArgs &a, int div, uint32_t grid, hipStream_t stream) {
   const bool traj = a.d_traj != nullptr;
@@ -622,19 +691,9 @@ hipError_t launch_ref_windowed(const RefArgs &a, int div, uint32_t grid, hipStre
   // SMMC_REF_KERNEL=tree (test / measurement knob): the tree form also for the lengths the hand-written one takes
   const char *env = std::getenv("SMMC_REF_KERNEL");
   const bool tree_always = env && !std::strcmp(env, "tree");
-  if (a.n_periods > kWindowedMax || tree_always) {
-    switch (div) {
-      case SMMC_DIV_FAST:
-        return traj ? launch_ref(ref_tree_kernel<kDivFast, true>, a, grid, lds, stream)
-                    : launch_ref(ref_tree_kernel<kDivFast, false>, a, grid, lds, stream);
-      case SMMC_DIV_CHECKED:
-        return traj ? launch_ref(ref_tree_kernel<kDivChecked, true>, a, grid, lds, stream)
-                    : launch_ref(ref_tree_kernel<kDivChecked, false>, a, grid, lds, stream);
-      default:
-        return traj ? launch_ref(ref_tree_kernel<kDivExact, true>, a, grid, lds, stream)
-                    : launch_ref(ref_tree_kernel<kDivExact, false>, a, grid, lds, stream);
-    }
-  }
+  if (a.n_periods > kWindowedMax || tree_always)
+    return a.n_periods <= static_cast<uint32_t>(kTreeMaxShort) ? launch_ref_tree<kTreeMaxShort>(a, div, traj, grid, lds, stream)
+                                                                : launch_ref_tree<kTreeMaxLong>(a, div, traj, grid, lds, stream);
   switch (div) {
     case SMMC_DIV_FAST:
       return traj ? launch_ref(ref_windowed_kernel<kDivFast, true>, a, grid, lds, stream)

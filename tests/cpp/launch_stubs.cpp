@@ -22,7 +22,7 @@ uint32_t values_hist_copies(uint32_t) { return 1; }
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins, int) { return (static_cast<size_t>(table_len) + n_bins) * 4u; }
 size_t keepdata_lds_bytes(uint32_t, int, int, int) { return 0; }
 hipError_t static_lds_bytes(size_t *bytes) { *bytes = 0; return hipSuccess; }
-uint32_t ref_windowed_max_outputs() { return 1077; }
+uint32_t ref_windowed_max_outputs() { return 1816; }
 size_t ref_workspace_bytes(uint32_t grid) { return static_cast<size_t>(grid) * 256 * 624 * 4; }
 size_t ref_windowed_lds_bytes(uint32_t table_len, bool) { return static_cast<size_t>(table_len) * 4; }
 hipError_t launch_ref_windowed(const RefArgs &, int, uint32_t, hipStream_t) { return hipErrorNoDevice; }

@@ -60,26 +60,32 @@ def test_ref_stream_instruction_counts_match_the_built_kernel(tmp_path):
     assert L.summary(runups[0])[0] == pytest.approx(bench.REF_VALU["runup_step"] * 8)
     assert bench.ref_valu_per_path(360) == pytest.approx(397 * 3 + 227 * 25 + 133 * 32)
     assert 0 < bench.ref_valu_per_path(0) < bench.ref_valu_per_path(1)
-    # ref_tree_kernel (455 .. 1077 periods): one written-out 4-output loop per stretch, in program order; the first two
-    # are the windowed kernel's own counts, every later stretch has more live chains (v_mad_u64_u32) and twists (v_bfi_b32)
-    tree = L.kernel_body(lines, "ref_tree_kernelILi0ELb0E")
+    # ref_tree_kernel (455 .. 1816 periods): one written-out 4-output loop per stretch, in program order; the first two
+    # are the windowed kernel's own counts; every later stretch has one more made word (v_bfi_b32: one per twist) and,
+    # every second or third stretch, one more live seed chain (v_mad_u64_u32) -- streams are shared between users
+    tree = L.kernel_body(lines, "ref_tree_kernelILi0ELb0ELi1816E")
     big = [c for _, c in L.loops(tree) if c.get("ds_read_b32") == 4]
     assert [L.summary(c)[0] for c in big] == [pytest.approx(4 * per) for _, per in bench.REF_TREE_STRETCHES]
-    assert [c["v_mad_u64_u32"] // 4 - 1 for c in big] == [2, 3, 4, 5, 6, 8, 9]      # live seed chains per stretch
-    assert [c["v_bfi_b32"] // 4 for c in big] == [1, 2, 3, 4, 5, 7, 8]              # twists per output
+    assert [c["v_mad_u64_u32"] // 4 - 1 for c in big] == [2, 3, 4, 4, 5, 5, 6, 6, 7, 7, 7, 8, 8, 8, 9, 9, 9]   # live seed chains
+    assert [c["v_bfi_b32"] // 4 for c in big] == list(range(1, 18))                                       # made words per output
     assert all("v_mul_lo_u32" not in c and "scratch_load_dword" not in c for c in big)
+    # the instantiation for paths of up to 1077 periods has the same loops for its seven stretches
+    short = [c for _, c in L.loops(L.kernel_body(lines, "ref_tree_kernelILi0ELb0ELi1077E")) if c.get("ds_read_b32") == 4]
+    assert [L.summary(c)[0] for c in short] == [L.summary(c)[0] for c in big[:7]]
     # the checked-divide variant (what the bundled table gets at 1000 periods) adds, at every check site, two float
     # compares, a select and the flag's v_cmp (bench.REF_CHECK_VALU per 8 periods) and nothing else on the VALU
     from collections import Counter
     def whole(sym):
         body = L.kernel_body(lines, sym)
         return Counter(x.split()[0] for x in body if x.strip() and x.strip()[0] not in ";." and not x.startswith("_Z"))
-    fast, chk = whole("ref_tree_kernelILi0ELb0E"), whole("ref_tree_kernelILi2ELb0E")
+    fast, chk = whole("ref_tree_kernelILi0ELb0ELi1077E"), whole("ref_tree_kernelILi2ELb0ELi1077E")
     sites = chk["v_cmp_ngt_f32_e64"] - fast["v_cmp_ngt_f32_e64"]
     assert sites > 0 and bench.REF_CHECK_VALU == 4
-    extra = {k: chk[k] - fast[k] for k in set(chk) | set(fast) if k.startswith("v_") and chk[k] != fast[k] and k != "v_mov_b32_e32"}
+    spill = ("v_mov_b32_e32", "v_readlane_b32", "v_writelane_b32")  # copies and scalar spills between the stretches, none in a loop
+    extra = {k: chk[k] - fast[k] for k in set(chk) | set(fast) if k.startswith("v_") and chk[k] != fast[k] and k not in spill}
+    assert not any(c.get("v_readlane_b32") or c.get("v_writelane_b32") for _, c in L.loops(tree))
     assert extra == {"v_cmp_ngt_f32_e64": sites, "v_cmp_nlt_f32_e32": sites, "v_cndmask_b32_e64": sites, "v_cmp_ne_u32_e32": sites}, extra
-    assert bench.ref_valu_per_path(1000) == pytest.approx(397 * 3 + 227 * 25 + 227 * 32 + 169 * 40 + 58 * 48 + 169 * 55 + 58 * 70 + 92 * 78)
+    assert bench.ref_valu_per_path(1000) == pytest.approx(397 * 3 + 227 * 25 + 227 * 32 + 169 * 40 + 58 * 45 + 169 * 52 + 58 * 57 + 92 * 65)
     assert bench.ref_valu_per_path(360) == pytest.approx(397 * 3 + 227 * 25 + 133 * 32)
 
 

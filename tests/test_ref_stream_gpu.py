@@ -102,12 +102,14 @@ def test_baseline_config0_size_matches_oracle_engine_r(eng, oracle, table):
 
 
 # 226/227/228: the windowed kernel's second stretch begins at output 227; 454 is the last length it takes; from 455 to
-# 1077 the tree kernel carries the recurrence on (its stretches begin at outputs 454, 623, 681, 850 and 908: lengths on
-# both sides of each, and lengths that leave one, two or three outputs to the remainder loop); from 1078 on the generic
-# kernel runs (624/625: its state wraps; 1248: twice)
+# 1816 the tree kernel carries the recurrence on (its stretches begin at outputs 454, 623, 681, 850, 908, 1077, 1135,
+# 1246, 1304, 1362, 1473, 1531, 1589, 1700, 1758: lengths on both sides of each, and lengths that leave one, two or
+# three outputs to the remainder loop); from 1817 on the generic kernel runs (624/625: its state wraps; 1248: twice)
 @pytest.mark.parametrize("p", [0, 1, 2, 7, 8, 9, 226, 227, 228, 229, 360, 437, 438, 439, 453, 454, 455, 456, 457, 458, 622, 623,
-                               624, 625, 626, 680, 681, 682, 683, 849, 850, 851, 852, 907, 908, 909, 910, 911, 1000, 1075, 1076,
-                               1077, 1078, 1079, 1248, 1300])
+                               624, 625, 626, 680, 681, 682, 683, 849, 850, 851, 852, 907, 908, 909, 910, 911, 1000, 1076,
+                               1077, 1078, 1079, 1134, 1135, 1136, 1245, 1246, 1247, 1248, 1300, 1303, 1304, 1305, 1361, 1362,
+                               1363, 1472, 1473, 1474, 1530, 1531, 1532, 1588, 1589, 1590, 1699, 1700, 1701, 1757, 1758, 1759,
+                               1814, 1815, 1816, 1817, 1818, 1900])
 def test_every_length_both_kernels(eng, oracle, table, p):
     n, seed0 = 2000 + 77, 2 ** 32 - 1000  # ragged; the seeds seed0 + id wrap past 2^32 inside the launch (path 1000 has seed 0)
     want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
@@ -123,7 +125,7 @@ def test_forced_kernels_and_divides_agree(table, oracle, monkeypatch, kernel, ex
     first two stretches are the same recurrence), "generic" the state-in-memory kernel for every length."""
     e = _engine(table, monkeypatch, SMMC_REF_KERNEL=kernel)
     try:
-        for p in (5, 300, 360, 700):
+        for p in (5, 300, 360, 700, 1400):
             n, seed0 = 30011, 99
             want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
             r = e.simulate(_sim(n, p, seed0, exact_div=exact_div))
@@ -215,7 +217,7 @@ def test_argument_errors(eng):
     assert st.count == 0 and int(st.hist.sum()) == 0
 
 
-@pytest.mark.parametrize("p", [0, 1, 31, 32, 33, 64, 227, 360, 454, 455, 700, 1000, 1077, 1078])
+@pytest.mark.parametrize("p", [0, 1, 31, 32, 33, 64, 227, 360, 454, 455, 700, 1000, 1077, 1078, 1500, 1816, 1817])
 def test_trajectories_of_the_reference_stream(eng, oracle, table, p):
     """mc_simulations_keepdata draws like mc_simulations (src/simulations.cpp:175-186: a generator per path,
     sample_returns_historical, many_updates): with SMMC_FLAG_STREAM_REF every row is many_updates of the table

@@ -1,6 +1,6 @@
 """Times the reference-stream kernels (SMMC_FLAG_STREAM_REF, smmc_ref_kernels.hip) with HIP events on the
 engine's stream: the windowed kernel at 360 periods (and the tree kernel forced onto the same shape), the tree
-kernel at 700 and 1000 periods beside the generic kernel forced onto them, the generic kernel at 1300, and the
+kernel at 700, 1000, 1300 and 1816 periods beside the generic kernel forced onto them, the generic kernel at 2000, and the
 default Philox table stream on the same shapes.  One JSON line per case.
 
 usage: bench_ref.py [n_paths_360] [n_paths_1000]
@@ -25,7 +25,10 @@ def main():
              ("philox table", n360, 360, 3, "auto"),
              ("ref tree", n1000, 700, "ref", "auto"), ("ref generic (forced)", n1000, 700, "ref", "generic"),
              ("ref tree", n1000, 1000, "ref", "auto"), ("ref generic (forced)", n1000, 1000, "ref", "generic"),
-             ("philox table", n1000, 1000, 3, "auto"), ("ref generic", n1000, 1300, "ref", "auto"))
+             ("philox table", n1000, 1000, 3, "auto"),
+             ("ref tree", n1000, 1300, "ref", "auto"), ("ref generic (forced)", n1000, 1300, "ref", "generic"),
+             ("ref tree", n1000, 1816, "ref", "auto"), ("ref generic (forced)", n1000, 1816, "ref", "generic"),
+             ("ref generic", n1000, 2000, "ref", "auto"))
     for name, n, p, stream, knob in cases:
         os.environ["SMMC_REF_KERNEL"] = knob  # read when an engine is created and (tree) at every launch
         eng = S.Engine(0)

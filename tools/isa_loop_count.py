@@ -69,8 +69,8 @@ TRAFFIC_KERNELS = {"gaussian": ("smmc_kernels.hip", "paths_kernel", "ILi1ELi0ELb
                    "table": ("smmc_kernels.hip", "paths_kernel", "ILi0ELi0ELb1E"),
                    "ref": ("smmc_ref_kernels.hip", "ref_windowed_kernel", "ILi0ELb0E"),
                    # the bundled table over 1000 periods cannot be proven safe for the fast divide: the checked variant runs
-                   "ref_tree": ("smmc_ref_kernels.hip", "ref_tree_kernel", "ILi2ELb0E")}
-REF_WINDOWED_MAX = 454  # longer paths of the reference stream (up to 1077 periods) run ref_tree_kernel
+                   "ref_tree": ("smmc_ref_kernels.hip", "ref_tree_kernel", "ILi2ELb0ELi1077E")}
+REF_WINDOWED_MAX = 454  # longer paths of the reference stream (up to 1816 periods) run ref_tree_kernel (two instantiations: <= 1077, <= 1816)
 
 
 def traffic_kernel_of(key):

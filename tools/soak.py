@@ -63,7 +63,7 @@ def main():
     t = S.Engine.make_sim(10_000_000, 360, S.MODE_TABLE, 11, n_bins=100, hist_lo=0.0, hist_hi=20000.0)
     r = S.Engine.make_sim(4_000_000, 360, S.MODE_TABLE, 11, n_bins=100, hist_lo=0.0, hist_hi=20000.0, stream="ref")
     rl = S.Engine.make_sim(400_000, 1000, S.MODE_TABLE, 11, n_bins=100, hist_lo=0.0, hist_hi=20000.0, stream="ref")
-    rg = S.Engine.make_sim(400_000, 1300, S.MODE_TABLE, 11, n_bins=100, hist_lo=0.0, hist_hi=20000.0, stream="ref")
+    rg = S.Engine.make_sim(400_000, 2000, S.MODE_TABLE, 11, n_bins=100, hist_lo=0.0, hist_hi=20000.0, stream="ref")
     k = S.Engine.make_sim(300_000, 360, S.MODE_GAUSSIAN, 11)
     out = torch.empty(10_000_000, dtype=torch.float32, device=eng.tdevice)
     host = torch.empty(10_000_000, dtype=torch.float32, pin_memory=True).numpy()
@@ -75,7 +75,7 @@ def main():
          lambda: eng.simulate(t, want_final=True, want_chunk_stats=True, want_stats=True))
     case("simulate reference stream (windowed + redo)", 400, lambda: eng.simulate(r, want_final=True, want_stats=True))
     case("simulate reference stream (tree kernel, 1000 periods)", 200, lambda: eng.simulate(rl, want_final=True, want_stats=True))
-    case("simulate reference stream (generic kernel, 1300 periods)", 200, lambda: eng.simulate(rg, want_final=True, want_stats=True))
+    case("simulate reference stream (generic kernel, 2000 periods)", 200, lambda: eng.simulate(rg, want_final=True, want_stats=True))
     case("simulate_to_host, pinned result", 400, lambda: eng.simulate_to_host(g, out=host, want_stats=True))
     for policy in ("whole", "chunk", "0"):  # read when an engine is created
         os.environ["SMMC_PIN_HOST"] = policy
