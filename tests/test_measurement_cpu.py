@@ -18,6 +18,12 @@ def asm(tmp_path_factory):
     return I.emit_asm(str(tmp_path_factory.mktemp("isa") / "smmc_kernels.s"))
 
 
+@pytest.fixture(scope="module")
+def ref_asm(tmp_path_factory):  # the reference-stream kernels: 40 s of hipcc, once for the module
+    import isa_loop_count as I
+    return I.emit_asm(str(tmp_path_factory.mktemp("isa_ref") / "smmc_ref_kernels.s"), "smmc_ref_kernels.hip")
+
+
 @pytest.mark.parametrize("mode", ["gaussian", "table"])
 def test_valu_instruction_counts_match_the_built_kernels(asm, mode):
     import bench
@@ -34,7 +40,7 @@ def test_valu_instruction_counts_match_the_built_kernels(asm, mode):
     assert c["v_bitop3_b32"] >= 15 and c["v_mad_u64_u32"] >= 16
 
 
-def test_ref_stream_instruction_counts_match_the_built_kernel(tmp_path):
+def test_ref_stream_instruction_counts_match_the_built_kernel(ref_asm):
     """bench.py --stream ref prices ref_windowed_kernel with three counts: per step of the seed run-up, per
     output below output 227 (two seed chains) and from 227 on (three chains, the earlier output generated
     again).  Re-derived from the kernel as it compiles now: the two written-out 4-output loops are the two
@@ -42,8 +48,7 @@ def test_ref_stream_instruction_counts_match_the_built_kernel(tmp_path):
     import bench
     import isa_loop_count as I
     import isa_loops as L
-    asm = I.emit_asm(str(tmp_path / "smmc_ref_kernels.s"), "smmc_ref_kernels.hip")
-    lines = open(asm).read().splitlines()
+    lines = open(ref_asm).read().splitlines()
     body = L.kernel_body(lines, "ref_windowed_kernelILi0ELb0E")
     found = sorted((L.summary(c)[0], c) for _, c in L.loops(body))
     (hi, c_hi), (lo, c_lo) = found[-1], found[-2]
@@ -105,21 +110,20 @@ def test_pmc_traffic_table_names_its_sources():
     assert bench.pmc_traffic("gaussian", 12345, 360, "all") == (None, None)
 
 
-def test_pmc_traffic_belongs_to_the_kernels_as_they_compile_now(asm, tmp_path):
+def test_pmc_traffic_belongs_to_the_kernels_as_they_compile_now(asm, ref_asm, tmp_path):
     """Every entry of profiles/pmc_traffic.json carries the fingerprint of the kernel that was profiled (its
     instruction mnemonics in program order) and a digest of the kernel sources + compiler flags.  A kernel
     change without a new PMC pass fails here; bench.py itself reports `traffic: null` for a stale entry."""
     import bench
     import isa_loop_count as I
     table = json.load(open(bench.PMC_TRAFFIC_FILE))
-    ref_asm = None
     for key, rec in table.items():
         mode = I.traffic_kernel_of(key)
         src, kernel, variant = I.TRAFFIC_KERNELS[mode]
         assert rec["kernel"] == kernel + variant
         path = asm
         if src != "smmc_kernels.hip":
-            ref_asm = ref_asm or I.emit_asm(str(tmp_path / "ref.s"), src)
+            assert src == "smmc_ref_kernels.hip"
             path = ref_asm
         assert rec["isa_fingerprint"] == I.fingerprint(path, variant, kernel), (
             f"{key}: the kernel changed since the PMC pass ({rec['source']}): run tools/profile_r03.sh again")
