@@ -50,8 +50,9 @@ extern "C" {
  * (Lemire's map with rejection), then update_fund.  With the seeds the reference's generators got, the
  * final values (and, with the keepdata entries, the trajectories: mc_simulations_keepdata draws the same
  * way, src/simulations.cpp:175-186) are the reference's, bit for bit.  Statistics and chunk outputs are
- * formed from the final values by a second pass.  About 3.5x the arithmetic of the default stream (624
- * words of generator state per path). */
+ * formed from the final values by a second pass.  About 3x the arithmetic of the default stream at 360
+ * periods and 4x at 1000 (the generator's 624 words of state per path are regenerated from seed chains, never
+ * stored, for paths of up to 1816 periods; longer paths keep them in device memory). */
 #define SMMC_FLAG_STREAM_REF 4u
 #define SMMC_FLAG_QUIET 8u /* no SMMC_VERBOSE phase lines for this request (the drop-in's warm-up run) */
 
