@@ -54,9 +54,12 @@ int main(int argc, char **argv) {
   std::printf("\n ],\n");
   // whole paths: explicit seed, table draw, fund * (100 + r) / 100 in binary32
   std::printf(" \"paths\": [\n");
-  // 226 / 227 / 228, 454 / 455, 623 / 624 / 625: the lengths at which the device kernels change how they obtain the
-  // generator's state words (tests/test_ref_stream_gpu.py compares the HIP result with these, not with the oracle)
-  const unsigned periods[] = {1, 4, 226, 227, 228, 360, 454, 455, 623, 624, 625, 1000};
+  // 226 / 227 / 228, 454 / 455, 623 / 624 / 625, 681, 850, 908, 1077 / 1078, 1135, 1304, 1531, 1816 / 1817: lengths at which
+  // the device kernels change how they obtain the generator's state words -- the stretches of ref_tree_kernel, the
+  // hand-over from its short instantiation to its long one and from that to ref_generic_kernel
+  // (tests/test_ref_stream_gpu.py compares the HIP result with these, not with the oracle)
+  const unsigned periods[] = {1, 4, 226, 227, 228, 360, 454, 455, 623, 624, 625, 681, 850, 908, 1000, 1077, 1078, 1135, 1304, 1531,
+                              1816, 1817, 2000};
   first = true;
   for (unsigned P : periods)
     for (uint32_t seed0 : {1000u, 4000000000u}) {

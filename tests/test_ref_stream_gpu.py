@@ -47,8 +47,11 @@ def test_golden_paths_of_the_real_libstdcxx(eng, table):
     """HIP result == what std::mt19937 + std::uniform_int_distribution<int> + update_fund gave."""
     pin = json.load(open(os.path.join(HERE, "golden", "libstdcxx_random.json")))
     assert pin["table_len"] == table.size
-    # 226 .. 228, 454 / 455, 623 .. 625: where the device kernels change how they obtain the generator's words
-    assert sorted({c["n_periods"] for c in pin["paths"]}) == [1, 4, 226, 227, 228, 360, 454, 455, 623, 624, 625, 1000]
+    # 226 .. 228, 454 / 455, 623 .. 625, 681, 850, 908, 1077 / 1078, 1135, 1304, 1531, 1816 / 1817: where the device kernels
+    # change how they obtain the generator's words (the windowed kernel's and the tree kernel's stretches, the tree
+    # kernel's two instantiations, the generic kernel beyond)
+    assert sorted({c["n_periods"] for c in pin["paths"]}) == [1, 4, 226, 227, 228, 360, 454, 455, 623, 624, 625, 681, 850, 908, 1000,
+                                                              1077, 1078, 1135, 1304, 1531, 1816, 1817, 2000]
     for case in pin["paths"]:
         r = eng.simulate(_sim(32, case["n_periods"], case["seed0"], cap=case["initial_capital"]))
         eng.sync()
