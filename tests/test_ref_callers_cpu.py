@@ -64,6 +64,7 @@ def test_csv_writers_byte_identical_to_reference_helpers(ref, tmp_path):
         v = np.array([1000.0, 1015.0, 992.1625, 993.154663, 1.0e9, 3.4e38, 1.17549435e-38], dtype=np.float32)
         ref.ref_write_data_file(b"theirs.csv", r.ctypes.data_as(C.c_void_p), r.size, v.ctypes.data_as(C.c_void_p), v.size)
         ref.ref_write_vector_file(b"outputs/theirs_vec.csv", v.ctypes.data_as(C.c_void_p), v.size)
+        C.CDLL(None).fflush(None)  # the reference's writer announces its file through C stdio: not at interpreter exit
         assert open("outputs/ours.csv", "rb").read() == open("outputs/theirs.csv", "rb").read()
         assert open("outputs/ours_vec.csv", "rb").read() == open("outputs/theirs_vec.csv", "rb").read()
         assert open("outputs/ours.csv").read().startswith("Returns,,1.5,-2.25,0.1,1e-07,12345.7,-0,\nValues,1000,1015,")
