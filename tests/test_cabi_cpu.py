@@ -123,3 +123,18 @@ def test_struct_sizes_agree_with_the_c_compiler(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     a, b = subprocess.check_output([str(exe)]).split()
     assert int(a) == C.sizeof(_lib.Sim) and int(b) == C.sizeof(_lib.Stats)
+
+
+def test_every_environment_knob_of_the_library_is_documented():
+    """Every SMMC_* variable the product reads (getenv in csrc/) has a row in INTEGRATION.md's table."""
+    import re
+    names = set()
+    csrc = os.path.join(ROOT, "stock_market_monte_carlo_amd", "csrc")
+    for dirpath, _, files in os.walk(csrc):
+        for fn in files:
+            if fn.endswith((".cpp", ".hip", ".h")):
+                names |= set(re.findall(r'getenv\("(SMMC_[A-Z0-9_]+)"\)', open(os.path.join(dirpath, fn)).read()))
+    assert len(names) >= 15
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
