@@ -134,6 +134,16 @@ def test_forced_kernels_and_divides_agree(table, oracle, monkeypatch, kernel, ex
             r = e.simulate(_sim(n, p, seed0, exact_div=exact_div))
             e.sync()
             assert np.array_equal(_bits(r.final.cpu().numpy()), _bits(want)), (kernel, exact_div, p)
+        # trajectories through the forced kernel too (the tree kernel's short instantiation at a windowed length)
+        n, p, seed0 = 777, 300, 4242
+        traj, fin = e.simulate_keepdata(_sim(n, p, seed0, exact_div=exact_div))
+        e.sync()
+        rows = traj.cpu().numpy()
+        want, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
+        assert np.array_equal(_bits(rows[:, -1]), _bits(want)) and np.array_equal(_bits(fin.cpu().numpy()), _bits(want))
+        for i in (0, 255, 256, n - 1):
+            idx = oracle.mt19937_indices((seed0 + i) & 0xFFFFFFFF, table.size, p)
+            assert np.array_equal(_bits(rows[i]), _bits(oracle.many_updates(1000.0, table[idx], p))), (kernel, i)
     finally:
         e.close()
 
