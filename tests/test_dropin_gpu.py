@@ -249,6 +249,11 @@ def test_reference_stream_through_the_drop_in(built, oracle, table):
     assert np.array_equal(np.array(d["quart"], dtype=np.float32), oracle.quartiles(want))
     # mc_simulations_keepdata draws the same way (src/simulations.cpp:175-186): its final values are the same paths'
     assert d["rows_ok"] and d["keep_hash"] == fnv(want[:3000])
+    # 1000 periods (BASELINE configs[4]'s length): the same entry points on ref_tree_kernel, keepdata included
+    out = subprocess.check_output([built, "6000", "1000"], cwd=ROOT, env=dict(os.environ, SMMC_STREAM="ref"))
+    dl = json.loads(out.decode().strip().splitlines()[-1])
+    long_want, _ = oracle.ref_mc_simulations(6000, 1000, 1000.0, table, 4242)
+    assert dl["gpu_hash"] == fnv(long_want) == dl["cpu_hash"] and dl["rows_ok"] and dl["keep_hash"] == fnv(long_want[:3000])
     # Python mirror
     got = S.mc_simulations(n, p, 1000.0, table, seed=4242, stream="ref")
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
