@@ -118,7 +118,7 @@ int main(int argc, char **argv) {
   // sample_returns_historical (:95-112: mt19937 + uniform_int_distribution, .at(idx)), then many_updates
   std::printf(" \"trajectories\": [\n");
   first = true;
-  for (unsigned P : {40u, 360u})
+  for (unsigned P : {40u, 360u, 1000u})  // 1000: ref_tree_kernel's trajectories
     for (uint32_t seed : {1000u, 4294967295u, 32569u}) {  // 32569: a path that rejects an output within 360 draws
       std::mt19937 rng(seed);
       std::uniform_int_distribution<int> uni(0, int(table.size()) - 1);

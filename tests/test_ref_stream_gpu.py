@@ -253,7 +253,7 @@ def test_trajectories_of_the_real_libstdcxx(eng, table):
     (src/simulations.cpp:95-112, 175-186), computed by the system libstdc++ -- every value of the row, incl. a path
     that rejects an output (seed 32569) and the largest 32-bit seed."""
     pin = json.load(open(os.path.join(HERE, "golden", "libstdcxx_random.json")))
-    assert len(pin["trajectories"]) == 6
+    assert len(pin["trajectories"]) == 9 and {c["n_periods"] for c in pin["trajectories"]} == {40, 360, 1000}  # 1000: the tree kernel
     for c in pin["trajectories"]:
         traj, final = eng.simulate_keepdata(_sim(3, c["n_periods"], c["seed"] - 1, cap=c["initial_capital"]))
         eng.sync()
