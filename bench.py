@@ -272,6 +272,13 @@ def pmc_traffic(mode, n, periods, outputs):
     return float(rec["bytes"]), rec.get("source")
 
 
+def _build_digest():
+    """sha256 of the sources + flags libsmmc_hip.so was built from (smmc_build_digest; the loader has already
+    checked it against the tree's sources)."""
+    from stock_market_monte_carlo_amd import _lib
+    return _lib.build_digest()
+
+
 # ---- launching the ranks ---------------------------------------------------------------------
 
 
@@ -330,9 +337,119 @@ def launch_ranks(n_ranks, argv):
             except subprocess.TimeoutExpired:
                 p.kill()
     # ONE JSON line on stdout; whatever else rank 0 printed there (gloo's connection banner) goes to stderr
-    for line in out0.decode(errors="replace").splitlines():
+    lines = out0.decode(errors="replace").splitlines()
+    for i, line in enumerate(lines):
+        if rc == 0 and line.startswith('{"metric"') and "--launch-check" not in argv and not os.environ.get("SMMC_BENCH_NO_GROUP"):
+            # the ranks are gone: the SAME workload once more through the one-process C-ABI launcher
+            # (smmc_group_*, RCCL all-reduce and host merge), from a fresh child of this GPU-less parent
+            try:
+                d = json.loads(line)
+                d["group_single_process"] = run_group_child(n_ranks, argv)
+                lines[i] = json.dumps(d)
+            except ValueError:
+                pass
+    for line in lines:
         print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
     return rc
+
+
+def group_child(args):
+    """`bench.py --group-child N ...`: the same workload through the C ABI's ONE-process launcher,
+    smmc_group_* (csrc/smmc_group.cpp; reference: mc_simulations_multi_gpu_launcher_async behind
+    mc_simulations_gpu(n_gpus), src/simulations.cu:576-680) -- one host thread and one engine per device, the
+    per-device records merged by ONE grouped ncclAllReduce (merge="rccl") and by the host loop (merge="host").
+    A fresh process started by the parent of the ranks (or by rank 0 after its process group is gone); prints
+    one JSON object.  Statistics-only for configs 0-3 (the group entry has no device-resident output), final
+    values into pinned host memory for config 4."""
+    import torch
+    import stock_market_monte_carlo_amd as S
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        print(json.dumps({"error": "no device visible"}))
+        return
+    G = args.group_child
+    preset = CONFIGS[args.config]
+    mode_name = args.mode or preset["mode"]
+    periods = args.periods if args.periods is not None else preset["periods"]
+    outputs = args.outputs or preset["outputs"]
+    total_paths, per_gpu = preset["total_paths"], preset["paths_per_gpu"]
+    if args.total_paths is not None:
+        total_paths, per_gpu = args.total_paths, None
+    elif args.paths_per_gpu is not None:
+        total_paths, per_gpu = None, args.paths_per_gpu
+    n_all = total_paths if total_paths is not None else per_gpu * G
+    to_host = outputs == "host"
+    mode = S.MODE_GAUSSIAN if mode_name == "gaussian" else S.MODE_TABLE
+    sim = S.Engine.make_sim(n_all, periods, mode, SEED, initial_capital=1000.0, gauss_mean=0.5, gauss_std=0.83333,
+                            n_bins=100, hist_lo=0.0, hist_hi=20000.0)
+    host = torch.empty(n_all, dtype=torch.float32, pin_memory=True).numpy() if to_host else None
+    out = {"devices": G, "visible_devices": n_dev, "paths": n_all, "n_periods": periods, "mode": mode_name,
+           "outputs": "host" if to_host else "stats", "steps": args.steps, "warmup": args.warmup,
+           "entry": "smmc_group_simulate (one process, one host thread + engine per device)"}
+    records = {}
+    for merge in ("rccl", "host"):
+        leg = {}
+        try:
+            if merge == "rccl" and n_dev < G:
+                raise RuntimeError(f"needs {G} distinct devices, {n_dev} visible")
+            devices = list(range(G)) if n_dev >= G else [i % n_dev for i in range(G)]
+            t0 = time.perf_counter()
+            grp = S.Group(devices, merge=merge)
+            leg["create_ms"] = (time.perf_counter() - t0) * 1e3
+            grp.set_table(load_table())
+            for _ in range(args.warmup):
+                grp.simulate(sim, out=host, want_final=to_host, want_stats=True)
+            merges = []
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                _, st, _ = grp.simulate(sim, out=host, want_final=to_host, want_stats=True)
+                merges.append(grp.timings()[2])
+            dt = time.perf_counter() - t0
+            engines_ms, comm_ms, _ = grp.timings()
+            grp.close()
+            assert st.count == n_all, (st.count, n_all)
+            records[merge] = (st.count, st.below, st.underflow, st.overflow, st.min, st.max, st.hist.tobytes(), st.sum, st.sumsq)
+            leg.update({"value": n_all * args.steps / dt, "unit": "paths/s", "ms_per_step": dt / args.steps * 1e3,
+                        "merge_ms": sum(merges) / len(merges), "engines_ms": engines_ms, "comm_init_ms": comm_ms,
+                        "device_list": devices, "result": {"mean": st.mean, "std": st.std, "below_initial": st.below}})
+        except Exception as ex:  # one leg failing must not lose the other
+            leg["error"] = f"{type(ex).__name__}: {ex}"
+        out[merge] = leg
+    if len(records) == 2:
+        out["rccl_equals_host_merge"] = records["rccl"] == records["host"]
+    print(json.dumps(out), flush=True)
+
+
+def run_group_child(n_gpus, argv, timeout_s=None):
+    """Starts `bench.py --group-child N <the run's own workload flags>` as a fresh child process (nothing here
+    execs), returns its JSON object or {"error": ...}.  Never raises: the headline line must not depend on it."""
+    timeout_s = timeout_s or float(os.environ.get("SMMC_BENCH_GROUP_TIMEOUT", "300"))
+    keep, skip = [], 0
+    for i, a in enumerate(argv):  # drop the launcher's own flags, keep the workload's
+        if skip:
+            skip -= 1
+            continue
+        if a in ("--gpus", "--backend", "--hash-shards"):
+            skip = 1
+            continue
+        if a.startswith(("--gpus=", "--backend=", "--hash-shards=")) or a in ("--rehearse-rccl", "--no-cpu-baseline"):
+            continue
+        keep.append(a)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
+                                                             "MASTER_ADDR", "MASTER_PORT", "SMMC_BENCH_CHILD",
+                                                             "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--group-child", str(n_gpus)] + keep, env=env,
+                           capture_output=True, text=True, timeout=timeout_s)
+        for line in reversed(p.stdout.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": f"no result (rc {p.returncode}): {p.stderr.strip()[-400:]}"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout_s:.0f} s"}
+    except Exception as ex:
+        return {"error": f"{type(ex).__name__}: {ex}"}
 
 
 def launch_check(args, world, rank):
@@ -415,11 +532,16 @@ def main():
                     help="outputs=host only, after the timed region: report a 64-bit digest of the final values in the "
                          "host buffer -- N > 1: every rank's own buffer, in rank order; N = 1: of the K contiguous shares "
                          "a K-rank run would hold -- so that a multi-rank run can be compared with a one-rank run bit for bit")
+    ap.add_argument("--group-child", type=int, default=0, metavar="N",
+                    help="internal: run the workload through ONE process's smmc_group over N devices (RCCL all-reduce and "
+                         "host merge) and print one JSON object; started by `--gpus N` after its ranks have finished")
     ap.add_argument("--launch-check", action="store_true",
                     help="CPU-only rehearsal of rank launch + rendezvous + the statistics gather (no GPU work)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.group_child:
+        return group_child(args)
 
     have_ranks = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not have_ranks:
@@ -618,6 +740,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if total_paths is not None else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "build_digest": _build_digest(),
             "config": {"workload": workload, "baseline_config": args.config if is_preset else None,
                        "paths_rank0": n, "paths_all_ranks": n_all, "n_periods": periods, "mode": mode_name,
                        "outputs": outputs, "seed": hex(SEED), "stream": args.stream,
@@ -649,11 +772,20 @@ def main():
             out["hbm_bound_kernels"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table)
-        print(json.dumps(out), flush=True)
 
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and not os.environ.get("SMMC_BENCH_CHILD") and not os.environ.get("SMMC_BENCH_NO_GROUP"):
+            # ranks made by an external launcher (torch.distributed.run): there is no GPU-less parent of ours, so
+            # rank 0 -- its timed region over, its collectives done, its engine closed -- starts the fresh child
+            # that runs the workload through the one-process C-ABI launcher (self-launched runs: the parent does)
+            eng.close()
+            del final
+            torch.cuda.empty_cache()
+            out["group_single_process"] = run_group_child(world, sys.argv[1:])
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SMMC_ABI_VERSION 3
+#define SMMC_ABI_VERSION 4
 
 /* return codes */
 #define SMMC_OK 0
@@ -55,6 +55,11 @@ extern "C" {
  * stored, for paths of up to 1816 periods; longer paths keep them in device memory). */
 #define SMMC_FLAG_STREAM_REF 4u
 #define SMMC_FLAG_QUIET 8u /* no SMMC_VERBOSE phase lines for this request (the drop-in's warm-up run) */
+/* smmc_engine_simulate_to_host: leave host_final as it is -- no page-locking for the call whatever SMMC_PIN_HOST
+ * says (the caller has pinned it, or has tried and failed: smmc_group_simulate registers the whole result once
+ * for all its devices and passes this to every shard, so that neighbouring shards never register the page
+ * their boundary falls in twice). */
+#define SMMC_FLAG_HOST_NOPIN 16u
 
 /* paths per chunk of the per-chunk mean/variance outputs: the reference's
  * THREADS_PER_BLOCK (src/simulations.cu:17), one (mean, variance) pair per block
@@ -118,6 +123,11 @@ void smmc_many_updates(const float *returns, float *totals, uint32_t n_periods);
 
 int smmc_abi_version(void);
 const char *smmc_last_error(void);
+/* 64 hex digits: sha256 over the compiler flags and every source and header this library was built from
+ * (stock_market_monte_carlo_amd/build.py: source_digest()).  The Python loader refuses a library whose digest
+ * differs from the sources beside it; bench.py prints it; the reference has no counterpart (its build is
+ * CMake's, CMakeLists.txt:99-103). */
+const char *smmc_build_digest(void);
 
 /* Number of visible HIP devices (0 and SMMC_OK when there is none). */
 int smmc_device_count(int *count);
@@ -328,7 +338,9 @@ int smmc_group_create(const int *devices, int n_devices, int merge, smmc_group *
 void smmc_group_destroy(smmc_group *g);
 int smmc_group_size(const smmc_group *g);
 
-/* smmc_engine_set_table on every device of the group. */
+/* smmc_engine_set_table on every device of the group.  A table identical to the one the devices hold is not
+ * uploaded again.  If a device fails, the devices may hold different tables: the group then refuses table-mode
+ * simulations (SMMC_ERR_INVALID) until a smmc_group_set_table has succeeded on all of them. */
 int smmc_group_set_table(smmc_group *g, const float *returns_percent, uint32_t n);
 
 /* Progress of smmc_group_simulate, summed over the devices (see smmc_engine_set_progress). */
@@ -336,7 +348,9 @@ int smmc_group_set_progress(smmc_group *g, smmc_progress_fn fn, void *user);
 
 /* smmc_engine_simulate_to_host for the whole request: device g simulates its contiguous share of the
  * global path ids sim->first_path .. first_path + n_paths - 1 and streams it to its place in the host
- * arrays (any may be NULL; a pageable host_final of 32 MiB or more is page-locked ONCE for all devices);
+ * arrays (any may be NULL; a pageable host_final of 32 MiB or more is page-locked ONCE for all devices, by the
+ * engine's own rules -- SMMC_PIN_HOST, both ends tested for "pinned already" -- and the shards run with
+ * SMMC_FLAG_HOST_NOPIN, also when that registration fails);
  * stats / hist receive the merged record.  The chunk arrays need every shard to start on a multiple
  * of SMMC_CHUNK paths: SMMC_ERR_INVALID otherwise.  Synchronous. */
 int smmc_group_simulate(smmc_group *g, const smmc_sim *sim, float *host_final, float *host_chunk_mean,

@@ -15,12 +15,13 @@ if os.environ.get("SMMC_LIB"):
     LIB_PATH = os.path.abspath(os.environ["SMMC_LIB"])
     print(f"stock_market_monte_carlo_amd: DEVELOPMENT library {LIB_PATH} (SMMC_LIB)", file=_sys.stderr)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MODE_TABLE = 0
 MODE_GAUSSIAN = 1
 FLAG_EXACT_DIV = 1
 FLAG_STREAM_V2 = 2  # counter stream v2 (round 1's) instead of v3
 FLAG_QUIET = 8
+FLAG_HOST_NOPIN = 16  # simulate_to_host: never page-lock host_final for the call
 FLAG_STREAM_REF = 4  # the reference CPU engine's own stream: per-path mt19937 + libstdc++ Lemire map (table mode)
 CHUNK = 256
 MAX_TABLE = 16384
@@ -72,6 +73,7 @@ SYMBOLS = [
     ("smmc_update_fund", C.c_float, [C.c_float, C.c_float]),
     ("smmc_many_updates", None, [C.c_void_p, C.c_void_p, C.c_uint32]),
     ("smmc_abi_version", C.c_int, []),
+    ("smmc_build_digest", C.c_char_p, []),
     ("smmc_vector_add", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
     ("smmc_last_error", C.c_char_p, []),
     ("smmc_device_count", C.c_int, [C.POINTER(C.c_int)]),
@@ -153,8 +155,34 @@ def lib():
             fn.argtypes = args
         if L.smmc_abi_version() != ABI_VERSION:
             raise SmmcError(f"libsmmc_hip.so has ABI {L.smmc_abi_version()}, binding expects {ABI_VERSION}")
+        _check_digest(L)
         _lib = L
     return _lib
+
+
+def build_digest():
+    """The digest the loaded library carries (smmc_build_digest)."""
+    return lib().smmc_build_digest().decode()
+
+
+def _check_digest(L):
+    """The library must have been built from the sources that lie beside it: its embedded digest (flags + content
+    of every source and header, build.source_digest()) against the tree's.  A stale product library is an error;
+    a development library (SMMC_LIB) only a loud warning.  Without the sources (a copied .so) there is nothing
+    to compare with and nothing is claimed."""
+    import sys
+    from . import build
+    if not os.path.isdir(build.CSRC):
+        return
+    have, want = L.smmc_build_digest().decode(), build.source_digest()
+    if have == want:
+        return
+    msg = (f"{LIB_PATH} was built from other sources or flags than this tree holds (library {have[:16]}..., sources "
+           f"{want[:16]}...): rebuild it with `python -m stock_market_monte_carlo_amd.build`")
+    if os.environ.get("SMMC_LIB"):
+        print(f"stock_market_monte_carlo_amd: WARNING: {msg}", file=sys.stderr)
+        return
+    raise SmmcError("stale library: " + msg)
 
 
 def check(rc):

@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include "smmc_host.h"
 #include "smmc_internal.h"
 
 namespace {
@@ -117,6 +118,13 @@ struct smmc_engine {
 
   float *d_bm_tables = nullptr;  // Box-Muller radius + trig tables (Gaussian mode)
   smmc::BlockPartial *d_partials = nullptr;  // max_grid entries
+  unsigned int *d_done_count = nullptr;      // paths_kernel's finished-workgroup counter: zero between launches
+  // Small launches: workgroups of a paths_kernel variant that are resident on the whole device at once (occupancy
+  // query, cached per variant key).  A launch of fewer than kSmallLaunchRounds x that many chunks is capped at the
+  // resident count: every workgroup then stages its draw tables once and strides over its chunks.
+  std::vector<std::pair<uint64_t, uint32_t>> resident_cache;
+  uint32_t small_launch_rounds = 8;          // SMMC_SMALL_LAUNCH_ROUNDS (0: never cap)
+  bool finalize_launch = false;              // SMMC_FINALIZE=launch: round 3's separate finalize_kernel (test knob: same bits)
 
   // simulate_to_host staging
   float *d_stage[2] = {nullptr, nullptr};
@@ -155,8 +163,8 @@ struct smmc_engine {
   size_t ev_used = 0;
 
   uint64_t host_chunk_paths = kHostChunkPaths;  // SMMC_HOST_CHUNK_PATHS
-  int pin_policy = 1;                           // SMMC_PIN_HOST: 0 never, 1 whole buffer (default), 2 chunk by chunk
-  uint64_t pin_min_bytes = 32ull << 20;
+  int pin_policy = smmc::kPinWhole;             // SMMC_PIN_HOST (smmc_host.h): never, whole buffer (default), chunk by chunk
+  uint64_t pin_min_bytes = smmc::kPinMinBytes;
   smmc_progress_fn progress_fn = nullptr;
   void *progress_user = nullptr;
 };
@@ -439,19 +447,46 @@ int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float 
   a.d_chunk_mean = d_chunk_mean;
   a.d_chunk_var = d_chunk_var;
   const uint64_t n_chunks = (s->n_paths + smmc::kBlock - 1) / smmc::kBlock;
-  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid));
+  uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid));
   if (d_stats) {
     SMMC_HIP(hipMemsetAsync(d_stats, 0, smmc_stats_bytes(s->n_bins), e->stream));
     a.partials = e->d_partials;
     a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
+    // the workgroup that finishes last folds the partials into the header (no finalize launch)
+    if (!e->finalize_launch) {
+      a.d_stats_out = static_cast<smmc_stats *>(d_stats);
+      a.done_count = e->d_done_count;
+    }
   }
   if (grid > 0) {
     const size_t lds = smmc::paths_lds_bytes(a.table_len, d_stats ? s->n_bins : 0u, a.stream);
     if (lds + 2048 > e->max_lds)
       return fail(SMMC_ERR_INVALID, "table + histogram need %zu bytes of LDS, device allows %zu", lds, e->max_lds);
+    const int div = divide_kind(e, s, true, &a.chk_lo, &a.chk_hi);
+    if (e->small_launch_rounds) {
+      // A launch of a few rounds of workgroups (BASELINE configs[0]: 3907 chunks, 1024 resident in Gaussian mode)
+      // gains nothing from queued workgroups -- there is no long tail to even out -- and pays the staging of
+      // the draw tables (24 KiB in Gaussian mode) once per chunk: cap it at what is resident.
+      const uint64_t key = (static_cast<uint64_t>(lds) << 16) | (static_cast<uint64_t>(a.stream & 3) << 12) |
+                           (static_cast<uint64_t>(a.mode & 3) << 8) | (static_cast<uint64_t>(a.table_len > 2048u) << 4) |
+                           static_cast<uint64_t>(div & 3);
+      uint32_t per_cu = 0;
+      bool known = false;
+      for (const auto &kv : e->resident_cache)
+        if (kv.first == key) {
+          per_cu = kv.second;
+          known = true;
+        }
+      if (!known) {
+        per_cu = smmc::paths_resident_per_cu(a, div, lds);
+        e->resident_cache.emplace_back(key, per_cu);
+      }
+      const uint64_t resident = static_cast<uint64_t>(per_cu) * e->compute_units;
+      if (resident && n_chunks > resident && n_chunks < resident * e->small_launch_rounds)
+        grid = static_cast<uint32_t>(std::min<uint64_t>(resident, grid));
+    }
     int rc = timing_begin(e);
     if (rc) return rc;
-    const int div = divide_kind(e, s, true, &a.chk_lo, &a.chk_hi);
     const hipError_t err = smmc::launch_paths(a, div, grid, lds, e->stream);
     if (err != hipSuccess) {
       (void)timing_end(e);
@@ -460,7 +495,7 @@ int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float 
     rc = timing_end(e);
     if (rc) return rc;
   }
-  if (d_stats)
+  if (d_stats && (grid == 0 || e->finalize_launch))  // no path at all (the record of an empty run), or the test knob
     SMMC_HIP(smmc::launch_finalize(e->d_partials, grid, static_cast<smmc_stats *>(d_stats), s->n_bins, e->stream));
   return SMMC_OK;
 }
@@ -542,10 +577,11 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     if (v >= 1024) e->host_chunk_paths = static_cast<uint64_t>(v) / 1024 * 1024;
     else if (v >= smmc::kBlock) e->host_chunk_paths = static_cast<uint64_t>(v) / smmc::kBlock * smmc::kBlock;  // tests
   }
-  if (const char *env = std::getenv("SMMC_PIN_HOST")) {  // see smmc_engine_simulate_to_host
-    if (!std::strcmp(env, "1") || !std::strcmp(env, "whole")) e->pin_policy = 1;
-    else if (!std::strcmp(env, "chunk")) e->pin_policy = 2;
-    else e->pin_policy = 0;
+  e->pin_policy = smmc::pin_policy_from_env();  // SMMC_PIN_HOST: see smmc_engine_simulate_to_host, smmc_host.h
+  if (const char *env = std::getenv("SMMC_FINALIZE")) e->finalize_launch = !std::strcmp(env, "launch");  // test knob, same bits
+  if (const char *env = std::getenv("SMMC_SMALL_LAUNCH_ROUNDS")) {  // tuning knob; the per-path results do not depend on it
+    const long v = std::strtol(env, nullptr, 10);
+    if (v >= 0 && v <= 1024) e->small_launch_rounds = static_cast<uint32_t>(v);
   }
   if (const char *env = std::getenv("SMMC_REF_KERNEL")) {  // test knob, results do not depend on it
     e->ref_kernel = !std::strcmp(env, "windowed") ? 1 : !std::strcmp(env, "generic") ? 2 : 0;
@@ -596,6 +632,8 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     err_tables = hipSetDevice(device);
     if (err_tables == hipSuccess)
       err_tables = hipMalloc(reinterpret_cast<void **>(&e->d_partials), sizeof(smmc::BlockPartial) * e->max_grid);
+    if (err_tables == hipSuccess) err_tables = hipMalloc(reinterpret_cast<void **>(&e->d_done_count), sizeof(unsigned int));
+    if (err_tables == hipSuccess) err_tables = hipMemset(e->d_done_count, 0, sizeof(unsigned int));
     // the Gaussian kernels read counter stream v3's tables at absolute LDS addresses from 0
     if (err_tables == hipSuccess) err_tables = smmc::static_lds_bytes(&static_lds);
     phase.mark("kernel attributes (code object loaded)");
@@ -659,6 +697,7 @@ void smmc_engine_destroy(smmc_engine *e) {
   if (e->d_ref_redo) (void)hipFree(e->d_ref_redo);
   if (e->d_ref_ws) (void)hipFree(e->d_ref_ws);
   if (e->d_partials) (void)hipFree(e->d_partials);
+  if (e->d_done_count) (void)hipFree(e->d_done_count);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -885,6 +924,22 @@ bool is_pinned(const void *p) {
   return false;
 }
 
+}  // namespace
+
+namespace smmc {
+PinPolicy pin_policy_from_env() {
+  const char *env = std::getenv("SMMC_PIN_HOST");
+  if (!env || !std::strcmp(env, "1") || !std::strcmp(env, "whole")) return kPinWhole;
+  if (!std::strcmp(env, "chunk")) return kPinChunk;
+  return kPinNever;
+}
+bool host_range_is_pinned(const void *p, uint64_t bytes) {
+  return p && bytes && is_pinned(p) && is_pinned(static_cast<const char *>(p) + (bytes - 1));
+}
+}  // namespace smmc
+
+namespace {
+
 // Page-locks whole pages [lo, hi) for the lifetime of the object, so that D2H copies into them run at the
 // pinned rate without the runtime's staging.  Failure is not an error -- the copy then takes the pageable
 // path -- but it is reported under SMMC_VERBOSE (a silently degraded pinned path).
@@ -933,7 +988,7 @@ std::vector<std::pair<void *, void *>> g_registered;  // (caller's pointer, page
 
 int smmc_host_register(void *host_ptr, uint64_t bytes) {
   if (!host_ptr || bytes == 0) return fail(SMMC_ERR_INVALID, "empty host buffer");
-  if (is_pinned(host_ptr) && is_pinned(static_cast<char *>(host_ptr) + bytes - 1)) return SMMC_OK;
+  if (smmc::host_range_is_pinned(host_ptr, bytes)) return SMMC_OK;
   const uintptr_t page = 4096, lo = reinterpret_cast<uintptr_t>(host_ptr) & ~(page - 1),
                   hi = (reinterpret_cast<uintptr_t>(host_ptr) + bytes + page - 1) & ~(page - 1);
   SMMC_HIP(hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterPortable));
@@ -1033,10 +1088,10 @@ int smmc_engine_simulate_to_host(smmc_engine *e, const smmc_sim *sim, float *hos
   // so a chunk's copy is cut where the next owner's pages begin: the tail piece (< 4 KiB) is its own copy.
   HostPin pin_all, pin_chunk[3];
   pin_all.drain = pin_chunk[0].drain = pin_chunk[1].drain = pin_chunk[2].drain = e->copy_stream;
-  const bool big_enough = host_final && sizeof(float) * n >= e->pin_min_bytes;
-  const bool already = big_enough && is_pinned(host_final) && is_pinned(host_final + (n - 1));
-  const bool pin_whole = big_enough && !already && e->pin_policy == 1;
-  const bool pin_chunks = big_enough && !already && e->pin_policy == 2 && chunk >= 2048;  // chunks span whole pages
+  const bool big_enough = host_final && sizeof(float) * n >= e->pin_min_bytes && !(sim->flags & SMMC_FLAG_HOST_NOPIN);
+  const bool already = big_enough && smmc::host_range_is_pinned(host_final, sizeof(float) * n);
+  const bool pin_whole = big_enough && !already && e->pin_policy == smmc::kPinWhole;
+  const bool pin_chunks = big_enough && !already && e->pin_policy == smmc::kPinChunk && chunk >= 2048;  // chunks span whole pages
   const uintptr_t page = 4096;
   auto page_floor = [&](const float *q) { return reinterpret_cast<uintptr_t>(q) & ~(page - 1); };
   auto pin_chunk_c = [&](uint64_t c) {  // the pages chunk c owns

@@ -28,6 +28,7 @@
 #include <unistd.h>
 
 #include "smmc.h"
+#include "smmc_host.h"
 #include "stock_market_monte_carlo/gpu.h"
 
 #ifndef MADV_POPULATE_WRITE
@@ -267,10 +268,11 @@ void resize_prefaulted_impl(std::vector<float> &v, size_t n) {
 // (profiles/r03/cold_start.txt has the phases).  The registration is released by PinnedResult.
 struct PinnedResult {
   void *ptr = nullptr;
+  // SMMC_PIN_HOST (smmc_host.h): only "whole" (the default) registers here, beside the engines' start-up.
+  // "chunk" is the engine's own policy -- it registers chunk by chunk ahead of its copies -- and a buffer found
+  // pinned would switch that off (the cold-start rows labelled "chunk" had measured "whole").
   void pin(std::vector<float> &v) {
-    const char *policy = std::getenv("SMMC_PIN_HOST");
-    const bool never = policy && std::strcmp(policy, "1") && std::strcmp(policy, "whole") && std::strcmp(policy, "chunk");
-    if (never || v.size() * sizeof(float) < (size_t(32) << 20)) return;
+    if (smmc::pin_policy_from_env() != smmc::kPinWhole || v.size() * sizeof(float) < smmc::kPinMinBytes) return;
     if (smmc_host_register(v.data(), v.size() * sizeof(float)) == SMMC_OK) ptr = v.data();  // failure: pageable copies
   }
   ~PinnedResult() {

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "smmc.h"
+#include "smmc_host.h"
 
 namespace {
 
@@ -106,6 +107,10 @@ struct smmc_group {
   smmc_progress_fn progress_fn = nullptr;
   void *progress_user = nullptr;
   double engines_ms = 0.0, comm_init_ms = 0.0, last_merge_ms = 0.0;
+  // the table every device holds (smmc_group_set_table): an identical one is not uploaded again, and a
+  // set_table that failed on some device leaves the group without a valid table until one succeeds everywhere
+  std::vector<float> table;
+  bool table_valid = true;  // false only between a failed smmc_group_set_table and the next successful one
 };
 
 namespace {
@@ -260,10 +265,24 @@ int smmc_group_size(const smmc_group *g) { return g ? static_cast<int>(g->device
 
 int smmc_group_set_table(smmc_group *g, const float *returns_percent, uint32_t n) {
   if (!g) return fail(SMMC_ERR_INVALID, "group is NULL");
+  if (!returns_percent || n == 0) return fail(SMMC_ERR_INVALID, "empty returns table");
+  // the same bytes as every device already holds: nothing to do (the drop-in sets the table before every call,
+  // twice per mc_simulations_gpu: for the warm-up run and for the run)
+  if (g->table_valid && g->table.size() == n && !std::memcmp(g->table.data(), returns_percent, sizeof(float) * n)) return SMMC_OK;
+  // From the first upload on the devices may disagree: a failure half way leaves the earlier devices with the
+  // new table and the later ones with the old.  The group then has NO valid table -- smmc_group_simulate
+  // refuses table mode -- until a set_table succeeds on every device.
+  g->table_valid = false;
+  g->table.clear();
   for (size_t i = 0; i < g->engines.size(); ++i) {
     const int rc = smmc_engine_set_table(g->engines[i], returns_percent, n);
-    if (rc != SMMC_OK) return rc;
+    if (rc != SMMC_OK) {
+      const std::string msg = smmc_last_error();
+      return fail(rc, "device %d: %s (the group's devices now hold different tables: set the table again)", g->devices[i], msg.c_str());
+    }
   }
+  g->table.assign(returns_percent, returns_percent + n);
+  g->table_valid = true;
   return SMMC_OK;
 }
 
@@ -321,6 +340,8 @@ int smmc_group_simulate(smmc_group *g, const smmc_sim *sim, float *host_final, f
   if (sim->struct_size != sizeof(smmc_sim))
     return fail(SMMC_ERR_INVALID, "smmc_sim.struct_size is %u, this library expects %zu", sim->struct_size, sizeof(smmc_sim));
   if (sim->n_bins > SMMC_MAX_BINS) return fail(SMMC_ERR_INVALID, "n_bins %u exceeds SMMC_MAX_BINS %d", sim->n_bins, SMMC_MAX_BINS);
+  if (sim->mode == SMMC_MODE_TABLE && !g->table_valid)
+    return fail(SMMC_ERR_INVALID, "the last smmc_group_set_table failed on some device: the devices hold different tables; set the table again");
   const int G = static_cast<int>(g->devices.size());
   const uint64_t n = sim->n_paths;
   const bool want_stats = stats != nullptr || hist != nullptr;
@@ -337,15 +358,17 @@ int smmc_group_simulate(smmc_group *g, const smmc_sim *sim, float *host_final, f
   std::vector<std::vector<char>> records(G, std::vector<char>(rec, 0));
 
   // One registration of the caller's result for all devices (each engine would otherwise register its
-  // own share, and neighbouring shares overlap in the page their boundary falls in: ADVICE r2).
+  // own share, and neighbouring shares overlap in the page their boundary falls in: ADVICE r2).  The rules are
+  // the engine's (smmc_host.h): policy, threshold, both ends tested for "pinned already".  With several
+  // devices "chunk" means "whole" here (chunk-wise ownership of pages is an engine's own business), and the
+  // shards are told not to register anything themselves -- also when this registration fails (the
+  // engines would then each try their own share and collide in the boundary pages).
   void *pinned = nullptr;
-  if (host_final && G > 1 && sizeof(float) * n >= (32ull << 20)) {
-    const char *policy = std::getenv("SMMC_PIN_HOST");
-    const bool never = policy && std::strcmp(policy, "1") && std::strcmp(policy, "whole") && std::strcmp(policy, "chunk");
-    hipPointerAttribute_t attr;
-    const bool already = hipPointerGetAttributes(&attr, host_final) == hipSuccess && attr.type != hipMemoryTypeUnregistered;
-    (void)hipGetLastError();
-    if (!never && !already) {
+  uint32_t shard_flags = 0;
+  if (host_final && G > 1) {
+    shard_flags = SMMC_FLAG_HOST_NOPIN;
+    const uint64_t bytes = sizeof(float) * n;
+    if (bytes >= smmc::kPinMinBytes && smmc::pin_policy_from_env() != smmc::kPinNever && !smmc::host_range_is_pinned(host_final, bytes)) {
       const uintptr_t page = 4096, lo = reinterpret_cast<uintptr_t>(host_final) & ~(page - 1),
                       hi = (reinterpret_cast<uintptr_t>(host_final + n) + page - 1) & ~(page - 1);
       if (hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterPortable) == hipSuccess) {
@@ -376,6 +399,7 @@ int smmc_group_simulate(smmc_group *g, const smmc_sim *sim, float *host_final, f
     smmc_sim part = *sim;
     part.first_path = sim->first_path + first;
     part.n_paths = count;
+    part.flags |= shard_flags;
     smmc_engine *e = g->engines[i];
     if (polled) {
       prog[i] = ShardProgress{&total, progress, g, &report_lock, 0};
@@ -444,6 +468,13 @@ int smmc_group_simulate(smmc_group *g, const smmc_sim *sim, float *host_final, f
           err = hipSetDevice(g->devices[i]);
           if (err == hipSuccess) err = hipStreamSynchronize(g->streams[i]);
         }
+      }
+      if (err != hipSuccess || res != ncclSuccess) {
+        // copies from records[i] and into `merged` (pageable vectors) may still be queued: nothing may
+        // touch them once this function has returned -- let every stream drain, errors ignored
+        for (int i = 0; i < G; ++i)
+          if (hipSetDevice(g->devices[i]) == hipSuccess) (void)hipStreamSynchronize(g->streams[i]);
+        (void)hipGetLastError();
       }
       if (prev >= 0) (void)hipSetDevice(prev);
       if (res != ncclSuccess) return fail(SMMC_ERR_HIP, "RCCL all-reduce of the statistics record failed: %s", r.GetErrorString(res));

@@ -452,6 +452,68 @@ __device__ __forceinline__ float simulate_path(const KernelArgs &k, const float 
   return total;
 }
 
+// ---- folding the workgroups' partial statistics -----------------------------------------------
+//
+// One order for every launch shape, so that the double sums of a given grid never depend on which kernel
+// folds them: kFoldWidth accumulators, accumulator v takes partials v, v + kFoldWidth, ... in ascending
+// order, then a binary tree over the accumulators (v += v + s for s = kFoldWidth / 2 ... 1).
+// finalize_kernel runs it with one thread per accumulator; the last workgroup of paths_kernel (256
+// threads) gives every thread the four accumulators t, t + 256, t + 512, t + 768 -- the tree's first two
+// levels then stay inside a thread -- and finishes the tree through LDS.  Same additions, same order,
+// same bits.
+constexpr int kFoldWidth = 1024;
+
+__device__ __forceinline__ void partial_identity(BlockPartial &t) {
+  t.sum = 0.0;
+  t.sumsq = 0.0;
+  t.count = t.below = t.underflow = t.overflow = 0ull;
+  t.min = __builtin_inff();
+  t.max = -__builtin_inff();
+}
+__device__ __forceinline__ void partial_add(BlockPartial &a, const BlockPartial &b) {
+  a.sum += b.sum;
+  a.sumsq += b.sumsq;
+  a.count += b.count;
+  a.below += b.below;
+  a.underflow += b.underflow;
+  a.overflow += b.overflow;
+  a.min = fminf(a.min, b.min);
+  a.max = fmaxf(a.max, b.max);
+}
+__device__ __forceinline__ void write_header(smmc_stats *out, const BlockPartial &r, uint32_t n_bins) {
+  out->count = r.count;
+  out->below = r.below;
+  out->underflow = r.underflow;
+  out->overflow = r.overflow;
+  out->sum = r.sum;
+  out->sumsq = r.sumsq;
+  out->min = r.min;
+  out->max = r.max;
+  out->n_bins = n_bins;
+  out->reserved = 0;
+}
+
+// The fold by ONE workgroup of kBlock threads; `sh` is kBlock BlockPartials of LDS.  Thread 0 returns the total.
+__device__ __forceinline__ BlockPartial fold_partials_block(const BlockPartial *partials, uint32_t n_partials, BlockPartial *sh) {
+  static_assert(kFoldWidth == 4 * kBlock, "a thread carries four accumulators");
+  BlockPartial acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    partial_identity(acc[q]);
+    for (uint32_t j = threadIdx.x + q * kBlock; j < n_partials; j += kFoldWidth) partial_add(acc[q], partials[j]);
+  }
+  partial_add(acc[0], acc[2]);  // tree level s = 512: v += v + 512
+  partial_add(acc[1], acc[3]);
+  partial_add(acc[0], acc[1]);  // s = 256
+  sh[threadIdx.x] = acc[0];
+  __syncthreads();
+  for (uint32_t s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) partial_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  return sh[0];
+}
+
 // ---- main kernel ---------------------------------------------------------------
 
 // Persistent workgroups; each iteration one chunk of 256 consecutive paths (one
@@ -579,6 +641,34 @@ __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
         if (c) atomicAdd(&k.d_hist[b], static_cast<unsigned long long>(c));
       }
     }
+    if (k.d_stats_out) {
+      // The workgroup that finishes last writes the record's header (round 3 launched finalize_kernel for
+      // that: a dependent launch boundary, 11 us of a 187 us step at 1e6 paths).  Release: this workgroup's
+      // partial is visible device-wide (the fence writes it back past this XCD's L2) before its count is;
+      // acquire: the last one sees every other workgroup's.  The fold's order is finalize_kernel's.
+      // (the flag lives in the reduction scratch, not in a static __shared__ word: the Gaussian kernels must have
+      // no static LDS, their draw tables sit at LDS address 0)
+      volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(red_scratch);
+      if (tid == 0) {
+        __threadfence();
+        const uint32_t done = __hip_atomic_fetch_add(k.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = done + 1u == gridDim.x ? 1u : 0u;
+      }
+      __syncthreads();
+      const bool is_last = *flag != 0u;  // workgroup-uniform
+      __syncthreads();                   // every thread has read the flag: the fold may overwrite it
+      if (is_last) {
+        __threadfence();
+        // kBlock BlockPartials (14 KiB: paths_lds_bytes reserves them) at the front of the dynamic allocation:
+        // the draw tables and the histogram are not read any more
+        BlockPartial *sh = reinterpret_cast<BlockPartial *>(lds_raw);
+        const BlockPartial total = fold_partials_block(k.partials, gridDim.x, sh);
+        if (tid == 0) {
+          write_header(k.d_stats_out, total, k.n_bins);
+          __hip_atomic_store(k.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        }
+      }
+    }
   }
 }
 
@@ -598,53 +688,17 @@ __global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const BlockPar
     }
   }
   __shared__ BlockPartial sh[kFinalizeBlock];
+  static_assert(kFinalizeBlock == kFoldWidth, "one thread per accumulator of the fold");
   BlockPartial t;
-  t.sum = 0.0;
-  t.sumsq = 0.0;
-  t.count = t.below = t.underflow = t.overflow = 0ull;
-  t.min = __builtin_inff();
-  t.max = -__builtin_inff();
-  for (uint32_t j = threadIdx.x; j < n_partials; j += kFinalizeBlock) {
-    const BlockPartial p = partials[j];
-    t.sum += p.sum;
-    t.sumsq += p.sumsq;
-    t.count += p.count;
-    t.below += p.below;
-    t.underflow += p.underflow;
-    t.overflow += p.overflow;
-    t.min = fminf(t.min, p.min);
-    t.max = fmaxf(t.max, p.max);
-  }
+  partial_identity(t);
+  for (uint32_t j = threadIdx.x; j < n_partials; j += kFinalizeBlock) partial_add(t, partials[j]);
   sh[threadIdx.x] = t;
   __syncthreads();
   for (uint32_t s = kFinalizeBlock / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      BlockPartial &a = sh[threadIdx.x];
-      const BlockPartial &b = sh[threadIdx.x + s];
-      a.sum += b.sum;
-      a.sumsq += b.sumsq;
-      a.count += b.count;
-      a.below += b.below;
-      a.underflow += b.underflow;
-      a.overflow += b.overflow;
-      a.min = fminf(a.min, b.min);
-      a.max = fmaxf(a.max, b.max);
-    }
+    if (threadIdx.x < s) partial_add(sh[threadIdx.x], sh[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const BlockPartial &r = sh[0];
-    out->count = r.count;
-    out->below = r.below;
-    out->underflow = r.underflow;
-    out->overflow = r.overflow;
-    out->sum = r.sum;
-    out->sumsq = r.sumsq;
-    out->min = r.min;
-    out->max = r.max;
-    out->n_bins = n_bins;
-    out->reserved = 0;
-  }
+  if (threadIdx.x == 0) write_header(out, sh[0], n_bins);
 }
 
 // ---- keepdata: every trajectory, path-major ------------------------------------
@@ -1151,7 +1205,9 @@ static size_t draw_table_words(uint32_t table_len, int stream) {
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins, int stream) {
   // [draw tables][histogram][pad to 8 bytes][red_scratch: 4 kWaves doubles][wave_part: kWaves BlockPartial]
   const size_t words = (draw_table_words(table_len, stream) + n_bins + 1u) & ~static_cast<size_t>(1);
-  return words * 4u + 4u * kWaves * sizeof(double) + kWaves * sizeof(BlockPartial);
+  const size_t bytes = words * 4u + 4u * kWaves * sizeof(double) + kWaves * sizeof(BlockPartial);
+  // ... or, for the workgroup that folds the partials at the end of a launch, kBlock BlockPartials from the front
+  return bytes > kBlock * sizeof(BlockPartial) ? bytes : kBlock * sizeof(BlockPartial);
 }
 bool table_is_dense(uint32_t table_len);
 // keepdata_kernel: tables + per wave 64 rows of (tile 16 | 32 columns + kDraws more slots, at the
@@ -1216,6 +1272,30 @@ static hipError_t launch_paths_mode(const KernelArgs &a, int div, uint32_t grid,
 }
 
 bool table_is_dense(uint32_t table_len) { return table_len <= kDenseMaxTable; }
+
+template <int kMode, bool kDense>
+static uint32_t resident_paths_mode(int div, size_t lds) {
+  int n = 0;
+  hipError_t err;
+  switch (div) {
+    case SMMC_DIV_FAST: err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, paths_kernel<kMode, kDivFast, kDense>, kBlock, lds); break;
+    case SMMC_DIV_CHECKED: err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, paths_kernel<kMode, kDivChecked, kDense>, kBlock, lds); break;
+    default: err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, paths_kernel<kMode, kDivExact, kDense>, kBlock, lds); break;
+  }
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n > 0 ? static_cast<uint32_t>(n) : 0u;
+}
+
+uint32_t paths_resident_per_cu(const KernelArgs &a, int div, size_t lds_bytes) {
+  if (a.mode != SMMC_MODE_TABLE)
+    return a.stream == 2 ? resident_paths_mode<kModeGaussianV2, false>(div, lds_bytes) : resident_paths_mode<SMMC_MODE_GAUSSIAN, false>(div, lds_bytes);
+  if (a.stream == 2)
+    return table_is_dense(a.table_len) ? resident_paths_mode<kModeTableV2, true>(div, lds_bytes) : resident_paths_mode<kModeTableV2, false>(div, lds_bytes);
+  return table_is_dense(a.table_len) ? resident_paths_mode<SMMC_MODE_TABLE, true>(div, lds_bytes) : resident_paths_mode<SMMC_MODE_TABLE, false>(div, lds_bytes);
+}
 
 hipError_t launch_paths(const KernelArgs &a, int div, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
   if (a.mode != SMMC_MODE_TABLE)

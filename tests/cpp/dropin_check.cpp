@@ -67,6 +67,12 @@ int main(int argc, char **argv) {
 
   std::vector<float> gauss;
   smmc::mc_simulations_gpu_gaussian(counter, n, periods, 1000.f, 0.5f, 0.83333f, gauss, 1);
+  if (const char *path = std::getenv("SMMC_DROPIN_DUMP_GAUSS")) {  // raw binary32 final values, for tests/test_gaussian_reference_gpu.py
+    if (FILE *f = std::fopen(path, "wb")) {
+      std::fwrite(gauss.data(), sizeof(float), gauss.size(), f);
+      std::fclose(f);
+    }
+  }
   smmc::Summary s = smmc::mc_summary(n, periods, 1000.f, true, table, 0.5f, 0.83333f, 1000.f, 50, 0.f, 5000.f, 1);
   std::uint64_t hist_total = 0;
   for (auto c : s.hist) hist_total += c;

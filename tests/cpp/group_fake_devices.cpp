@@ -1,0 +1,231 @@
+// group_fake_devices.cpp -- smmc_group_* and the C++ drop-in's n_gpus calls over THREE distinct (fake) devices,
+// built with ThreadSanitizer and with AddressSanitizer (tests/test_group_fake_devices_cpu.py; runtime:
+// tests/cpp/fake_hip.cpp, kernels: tests/cpp/launch_fake.cpp).  The reference's counterpart is
+// mc_simulations_multi_gpu_launcher_async (src/simulations.cu:576-655) behind mc_simulations_gpu(n_gpus).
+//
+// A fake launch writes fake_path_value(global id) where the kernel writes a final value, so "every id exactly
+// once, in its place" is checkable for any sharding and chunking.
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "smmc.h"
+#include "stock_market_monte_carlo/simulations.h"
+
+extern "C" float fake_path_value(uint64_t id, uint32_t key0, uint32_t key1, uint32_t n_periods, float capital);
+extern "C" void fake_hip_fail_mallocs_on(int device);
+extern "C" size_t fake_hip_live_allocations(void);
+extern "C" size_t fake_hip_registered_ranges(void);
+
+static int fails = 0;
+#define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
+
+static smmc_sim make_sim(int mode, uint64_t seed, uint64_t first, uint64_t n, uint32_t periods, uint32_t bins) {
+  smmc_sim s;
+  std::memset(&s, 0, sizeof s);
+  s.struct_size = sizeof s;
+  s.mode = mode;
+  s.seed = seed;
+  s.first_path = first;
+  s.n_paths = n;
+  s.n_periods = periods;
+  s.initial_capital = 1000.f;
+  s.gauss_mean = 0.5f;
+  s.gauss_std = 0.83333f;
+  s.n_bins = bins;
+  s.hist_lo = 0.f;
+  s.hist_hi = 2500.f;
+  s.below_threshold = 1000.f;
+  return s;
+}
+
+struct Seen {
+  std::atomic<int64_t> last{-1};
+  std::atomic<int> calls{0};
+  std::atomic<bool> monotone{true};
+  static void on(void *user, int64_t finished) {
+    Seen *s = static_cast<Seen *>(user);
+    if (finished < s->last.load()) s->monotone = false;
+    s->last = finished;
+    ++s->calls;
+  }
+};
+
+// the record of ids [first, first + n) computed straight from the definition
+static void expected_record(const smmc_sim &s, smmc_stats *st, std::vector<uint64_t> &hist) {
+  std::memset(st, 0, sizeof *st);
+  st->min = INFINITY;
+  st->max = -INFINITY;
+  hist.assign(s.n_bins, 0);
+  const double inv = s.n_bins ? double(s.n_bins) / (double(s.hist_hi) - double(s.hist_lo)) : 0.0;
+  for (uint64_t i = 0; i < s.n_paths; ++i) {
+    const float v = fake_path_value(s.first_path + i, uint32_t(s.seed), uint32_t(s.seed >> 32), s.n_periods, s.initial_capital);
+    st->count += 1;
+    st->below += v < s.below_threshold;
+    st->min = std::fmin(st->min, v);
+    st->max = std::fmax(st->max, v);
+    if (v < s.hist_lo) st->underflow += 1;
+    else if (v < s.hist_hi) {
+      int b = int((double(v) - s.hist_lo) * inv);
+      hist[b < int(s.n_bins) - 1 ? b : int(s.n_bins) - 1] += 1;
+    } else st->overflow += 1;
+  }
+}
+
+static bool values_in_place(const std::vector<float> &out, const smmc_sim &s) {
+  for (uint64_t i = 0; i < s.n_paths; ++i)
+    if (out[i] != fake_path_value(s.first_path + i, uint32_t(s.seed), uint32_t(s.seed >> 32), s.n_periods, s.initial_capital)) {
+      std::printf("value %llu is not its id's\n", (unsigned long long)i);
+      return false;
+    }
+  return true;
+}
+
+int main() {
+  int n_dev = 0;
+  EXPECT(smmc_device_count(&n_dev) == SMMC_OK && n_dev == 3);
+  const int devices[3] = {0, 1, 2};
+  smmc_group *g = nullptr;
+  EXPECT(smmc_group_create(devices, 3, SMMC_MERGE_HOST, &g) == SMMC_OK && smmc_group_size(g) == 3);
+  if (!g) return 1;
+  std::vector<float> table(1127);
+  for (size_t i = 0; i < table.size(); ++i) table[i] = 0.01f * float(i) - 5.f;
+  EXPECT(smmc_group_set_table(g, table.data(), uint32_t(table.size())) == SMMC_OK);
+  EXPECT(smmc_group_set_table(g, table.data(), uint32_t(table.size())) == SMMC_OK);  // identical: not uploaded again
+
+  // 1. 36 MB of final values (above the pinning threshold: the group registers the whole buffer once, its shards
+  //    must not register anything), three shards with a remainder, several chunks per shard, statistics, a
+  //    progress callback AND a polled counter, ids beyond 2^32
+  {
+    const uint64_t n = 9000001;
+    smmc_sim s = make_sim(SMMC_MODE_TABLE, 0x1234567ull << 20, (1ull << 33) + 5, n, 360, 64);
+    std::vector<float> out(n + 2, -7.f);  // out + 1: not page aligned
+    smmc_stats st;
+    std::vector<uint64_t> hist(64), want_hist;
+    Seen seen;
+    volatile int64_t counter = -1;
+    EXPECT(smmc_group_set_progress(g, &Seen::on, &seen) == SMMC_OK);
+    std::atomic<bool> stop{false};
+    std::atomic<int> poll_steps{0};
+    std::thread poller([&] {  // a GUI thread polling the counter while the engines run (visualize_returns_cpu_v2.cpp:360-376)
+      int64_t prev = -1;
+      while (!stop) {
+        const int64_t c = __atomic_load_n(const_cast<int64_t *>(&counter), __ATOMIC_ACQUIRE);
+        if (c != prev) ++poll_steps;
+        prev = c;
+        std::this_thread::yield();
+      }
+    });
+    const int rc = smmc_group_simulate(g, &s, out.data() + 1, nullptr, nullptr, &counter, &st, hist.data());
+    stop = true;
+    poller.join();
+    EXPECT(rc == SMMC_OK);
+    if (rc != SMMC_OK) std::printf("%s\n", smmc_last_error());
+    EXPECT(out[0] == -7.f && out[n + 1] == -7.f);
+    std::vector<float> body(out.begin() + 1, out.begin() + 1 + n);
+    EXPECT(values_in_place(body, s));
+    smmc_stats want;
+    expected_record(s, &want, want_hist);
+    EXPECT(st.count == n && st.below == want.below && st.underflow == want.underflow && st.overflow == want.overflow);
+    EXPECT(st.min == want.min && st.max == want.max && hist == want_hist && st.n_bins == 64);
+    EXPECT(seen.monotone && seen.last == int64_t(n) && seen.calls >= 6 && counter == int64_t(n) && poll_steps >= 2);
+    EXPECT(fake_hip_registered_ranges() == 0);  // the group's registration is released again
+    (void)smmc_group_set_progress(g, nullptr, nullptr);
+    uint64_t first, count, total = 0;
+    for (int i = 0; i < 3; ++i) {
+      EXPECT(smmc_group_shard(g, n, i, &first, &count) == SMMC_OK && first == total);
+      total += count;
+    }
+    EXPECT(total == n);
+  }
+
+  // 2. chunk means / variances need shards that start on a multiple of 256 paths; Gaussian mode needs no table
+  {
+    const uint64_t n = 3 * 256 * 700;
+    smmc_sim s = make_sim(SMMC_MODE_GAUSSIAN, 99, 0, n, 36, 0);
+    std::vector<float> out(n), cm(n / 256), cv(n / 256);
+    EXPECT(smmc_group_simulate(g, &s, out.data(), cm.data(), cv.data(), nullptr, nullptr, nullptr) == SMMC_OK);
+    EXPECT(values_in_place(out, s));
+    bool ok = true;
+    for (uint64_t c = 0; c < n / 256; ++c) {
+      double s1 = 0, s2 = 0;
+      for (int j = 0; j < 256; ++j) { const double v = out[c * 256 + j]; s1 += v; s2 += v * v; }
+      const double mean = s1 / 256, var = s2 / 256 - mean * mean;
+      ok = ok && cm[c] == float(mean) && cv[c] == float(var > 0 ? var : 0);
+    }
+    EXPECT(ok);
+    smmc_sim odd = make_sim(SMMC_MODE_GAUSSIAN, 99, 0, n + 1, 36, 0);  // shard 1 would start at 179201
+    std::vector<float> out2(n + 1);
+    EXPECT(smmc_group_simulate(g, &odd, out2.data(), cm.data(), nullptr, nullptr, nullptr, nullptr) == SMMC_ERR_INVALID);
+  }
+
+  // 3. two callers at once on two groups over the same devices (the reference's GUI runs two engines side by
+  //    side, examples/visualize_returns_cpu_v2.cpp:185-202)
+  {
+    smmc_group *g2 = nullptr;
+    EXPECT(smmc_group_create(devices, 3, SMMC_MERGE_HOST, &g2) == SMMC_OK);
+    EXPECT(smmc_group_set_table(g2, table.data(), uint32_t(table.size())) == SMMC_OK);
+    const uint64_t n = 1500007;
+    smmc_sim sa = make_sim(SMMC_MODE_TABLE, 7, 0, n, 360, 16), sb = make_sim(SMMC_MODE_TABLE, 8, 1000, n, 36, 16);
+    std::vector<float> oa(n), ob(n);
+    smmc_stats sta, stb;
+    std::vector<uint64_t> ha(16), hb(16);
+    int rca = -1, rcb = -1;
+    std::thread ta([&] { rca = smmc_group_simulate(g, &sa, oa.data(), nullptr, nullptr, nullptr, &sta, ha.data()); });
+    std::thread tb([&] { rcb = smmc_group_simulate(g2, &sb, ob.data(), nullptr, nullptr, nullptr, &stb, hb.data()); });
+    ta.join();
+    tb.join();
+    EXPECT(rca == SMMC_OK && rcb == SMMC_OK && values_in_place(oa, sa) && values_in_place(ob, sb));
+    EXPECT(sta.count == n && stb.count == n);
+    smmc_group_destroy(g2);
+  }
+
+  // 4. a set_table that fails on the second device: the devices hold different tables, table mode is refused
+  //    until a set_table has succeeded everywhere; Gaussian mode is not affected
+  {
+    std::vector<float> other(table);
+    other[0] += 1.f;
+    fake_hip_fail_mallocs_on(1);
+    std::vector<float> longer(2000, 1.f);  // another length: the engine has to allocate
+    EXPECT(smmc_group_set_table(g, longer.data(), uint32_t(longer.size())) != SMMC_OK);
+    EXPECT(std::strstr(smmc_last_error(), "different tables") != nullptr);
+    fake_hip_fail_mallocs_on(-1);
+    smmc_sim s = make_sim(SMMC_MODE_TABLE, 7, 0, 3000, 36, 0);
+    std::vector<float> out(3000);
+    EXPECT(smmc_group_simulate(g, &s, out.data(), nullptr, nullptr, nullptr, nullptr, nullptr) == SMMC_ERR_INVALID);
+    smmc_sim sg = make_sim(SMMC_MODE_GAUSSIAN, 7, 0, 3000, 36, 0);
+    EXPECT(smmc_group_simulate(g, &sg, out.data(), nullptr, nullptr, nullptr, nullptr, nullptr) == SMMC_OK);
+    EXPECT(smmc_group_set_table(g, other.data(), uint32_t(other.size())) == SMMC_OK);
+    EXPECT(smmc_group_simulate(g, &s, out.data(), nullptr, nullptr, nullptr, nullptr, nullptr) == SMMC_OK && values_in_place(out, s));
+  }
+  smmc_group_destroy(g);
+
+  // 5. the C++ drop-in's n_gpus calls (mc_simulations_gpu :661-680 of the reference): three devices, the callee
+  //    sizes the result, the remainder is kept, the counter ends at N
+  {
+    smmc::fix_seed(true, 4242);
+    std::atomic<long> counter{0};
+    std::vector<float> totals;
+    const long n = 9000003;
+    mc_simulations_gpu(counter, n, 360, 1000.f, table, totals, 3);
+    EXPECT(long(totals.size()) == n && counter == n);
+    smmc_sim s = make_sim(SMMC_MODE_TABLE, 4242, 0, uint64_t(n), 360, 0);
+    EXPECT(values_in_place(totals, s));
+    smmc::Summary sum = smmc::mc_summary(n, 360, 1000.f, false, table, 0.f, 0.f, 1000.f, 64, 0.f, 2500.f, 3);
+    smmc_sim sh = make_sim(SMMC_MODE_TABLE, 4242, 0, uint64_t(n), 360, 64);
+    smmc_stats want;
+    std::vector<uint64_t> want_hist;
+    expected_record(sh, &want, want_hist);
+    EXPECT(sum.count == uint64_t(n) && sum.below == want.below && sum.hist == want_hist && sum.min == want.min && sum.max == want.max);
+    bool threw = false;
+    try { mc_simulations_gpu(counter, 10, 36, 1000.f, table, totals, 4); } catch (const std::invalid_argument &) { threw = true; }
+    EXPECT(threw);  // four shards on three devices
+  }
+  if (fake_hip_registered_ranges() != 0) { std::printf("FAIL: %zu host ranges still registered\n", fake_hip_registered_ranges()); ++fails; }
+  std::printf(fails ? "group_fake_devices: %d failure(s)\n" : "group_fake_devices: ok\n", fails);
+  return fails ? 1 : 0;
+}

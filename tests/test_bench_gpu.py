@@ -142,3 +142,71 @@ def test_ranks_made_by_torchrun_run_the_real_step():
     assert two["result"]["hist_total"] == one["result"]["hist_total"] == total
     assert two["result"]["below_initial"] == one["result"]["below_initial"]
     assert two["result"]["mean"] == pytest.approx(one["result"]["mean"], rel=1e-12)
+
+
+def _check_group_leg(leg, n_all, result):
+    assert "error" not in leg, leg
+    assert leg["value"] > 0 and leg["ms_per_step"] > 0 and leg["merge_ms"] >= 0 and leg["engines_ms"] > 0
+    assert leg["result"]["below_initial"] == result["below_initial"]
+    assert leg["result"]["mean"] == pytest.approx(result["mean"], rel=1e-12)
+
+
+def test_self_launched_run_attaches_the_one_process_group_launcher():
+    """after the ranks of `python bench.py --gpus 2` have finished, their GPU-less parent
+    starts ONE fresh child that runs the same workload through the C ABI's one-process launcher (smmc_group_*:
+    one host thread + engine per device) and attaches `group_single_process` to rank 0's line.  On this
+    one-GPU box both shards sit on device 0, so the host-merge leg runs and the RCCL leg (which needs distinct
+    devices) reports why it cannot -- as an error string inside the object, never as a lost line."""
+    total = 5_000_001
+    two = _run("--gpus", "2", "--backend", "gloo", "--config", "3", "--total-paths", str(total), "--steps", "2", "--warmup", "1",
+               timeout=600)
+    g = two["group_single_process"]
+    assert g["devices"] == 2 and g["paths"] == total and g["outputs"] == "stats" and g["n_periods"] == 360
+    _check_group_leg(g["host"], total, two["result"])
+    assert g["host"]["device_list"] == [0, 0] and g["host"]["comm_init_ms"] == 0.0
+    assert "distinct devices" in g["rccl"]["error"]
+    # config 4's shape: final values into pinned host memory through every shard's pipeline
+    total4 = 2_000_001
+    four = _run("--gpus", "2", "--backend", "gloo", "--config", "4", "--total-paths", str(total4), "--steps", "2", "--warmup", "1",
+                timeout=600)
+    g4 = four["group_single_process"]
+    assert g4["outputs"] == "host" and g4["n_periods"] == 1000 and g4["paths"] == total4
+    assert "error" not in g4["host"] and g4["host"]["value"] > 0
+
+
+def test_group_child_with_one_device_runs_both_merge_back_ends_to_the_same_bits():
+    """`bench.py --group-child 1`: one device allows the RCCL leg too (ncclCommInitAll over one device, the
+    grouped all-reduce): its merged record equals the host merge's bit for bit, the communicator's set-up
+    time is reported, and both equal the plain one-rank run of the workload."""
+    total = 3_000_001
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, BENCH, "--group-child", "1", "--config", "3", "--total-paths", str(total), "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    g = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    one = _run("--config", "3", "--total-paths", str(total), "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    _check_group_leg(g["host"], total, one["result"])
+    _check_group_leg(g["rccl"], total, one["result"])
+    assert g["rccl_equals_host_merge"] is True and g["rccl"]["comm_init_ms"] > 0
+
+
+def test_ranks_made_by_torchrun_attach_the_group_launcher_from_rank_zero():
+    """Under an external launcher there is no GPU-less parent of ours: rank 0 -- timed region over, process
+    group destroyed, engine closed -- starts the fresh child itself."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    total = 3_000_001
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--backend", "gloo",
+                        "--config", "3", "--total-paths", str(total), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    two = json.loads(lines[0])
+    g = two["group_single_process"]
+    assert two["launcher"] == "external" and g["devices"] == 2 and g["paths"] == total
+    _check_group_leg(g["host"], total, two["result"])

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(L):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(L, name), name
-    assert L.smmc_abi_version() == _lib.ABI_VERSION == 3
+    assert L.smmc_abi_version() == _lib.ABI_VERSION == 4
     # and nothing else with the C ABI's prefix leaves the library (helpers shared between its translation
     # units are hidden)
     import subprocess

@@ -1,0 +1,49 @@
+"""smmc_group_* and the C++ drop-in's n_gpus calls with THREE distinct devices, on the CPU, under ThreadSanitizer
+and AddressSanitizer + UBSan (the pool gives one GPU, so the per-device host threads, the
+once-only registration of the caller's buffer and the record merge had only ever run with one device or with one
+device listed several times).  The devices are tests/cpp/fake_hip.cpp's -- host memory behind the HIP runtime's
+own entry points, linked instead of libamdhip64 -- and a "launch" (tests/cpp/launch_fake.cpp) writes a known
+function of the global path id, so tests/cpp/group_fake_devices.cpp can check that every id of a sharded, chunked,
+multi-threaded run landed in its place exactly once and that the merged record is the record of all of them.
+Reference: mc_simulations_multi_gpu_launcher_async, src/simulations.cu:576-655."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = os.path.join(ROOT, "oracle", "_san")
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_san/group_fake_tsan", "_san/group_fake_asan"],
+                          stdout=subprocess.DEVNULL)
+
+
+def _run(exe, **env):
+    e = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+             TSAN_OPTIONS="halt_on_error=1", SMMC_VERBOSE="1", FAKE_HIP_DEVICES="3")
+    for k in ("SMMC_PIN_HOST", "SMMC_HOST_CHUNK_PATHS", "SMMC_DEVICE_MAP", "SMMC_GROUP_MERGE", "SMMC_SEED", "SMMC_STREAM"):
+        e.pop(k, None)
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([os.path.join(SAN, exe)], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    text = r.stdout + r.stderr
+    assert r.returncode == 0 and "group_fake_devices: ok" in r.stdout, text[-3000:]
+    assert "Sanitizer" not in text and "runtime error" not in text, text[-3000:]
+    # SMMC_VERBOSE reports a registration that fell back to pageable copies: with one owner per page there is none
+    assert "hipHostRegister" not in text, text[-3000:]
+    return text
+
+
+@pytest.mark.parametrize("exe", ["group_fake_tsan", "group_fake_asan"])
+def test_three_device_group_and_dropin(built, exe):
+    text = _run(exe)
+    assert "group of 3 device(s)" in text and "shard 2 on device 2" in text
+
+
+@pytest.mark.parametrize("env", [dict(SMMC_PIN_HOST="chunk"), dict(SMMC_PIN_HOST="0"), dict(SMMC_HOST_CHUNK_PATHS=65536),
+                                 dict(SMMC_PIN_HOST="chunk", SMMC_HOST_CHUNK_PATHS=131072)])
+def test_pinning_policies_and_chunk_lengths_with_three_devices(built, env):
+    """Every SMMC_PIN_HOST policy and short chunks (46 per shard): the same checks; under ThreadSanitizer."""
+    _run("group_fake_tsan", **env)

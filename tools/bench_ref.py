@@ -3,7 +3,7 @@ engine's stream: the windowed kernel at 360 periods (and the tree kernel forced 
 kernel at 700, 1000, 1300 and 1816 periods beside the generic kernel forced onto them, the generic kernel at 2000, and the
 default Philox table stream on the same shapes.  One JSON line per case.
 
-usage: bench_ref.py [n_paths_360] [n_paths_1000]
+usage: bench_ref.py [n_paths_360] [n_paths_1000]   |   bench_ref.py --traj
 """
 import json
 import os
@@ -16,8 +16,51 @@ import stock_market_monte_carlo_amd as S  # noqa: E402
 from tests.conftest import load_table  # noqa: E402
 
 
+def traj_cases():
+    """Reference-stream keepdata (mc_simulations_keepdata's own stream, src/simulations.cpp:175-186): the windowed kernel
+    at 4e6 x 361 values and the tree kernel at 1.5e6 x 1001, the Philox table stream's keepdata beside them.  HBM-bound:
+    4 (P + 1) bytes per path."""
+    import ctypes as C
+    import torch
+    from stock_market_monte_carlo_amd import _lib
+    table = load_table()
+    cases = (("ref windowed traj", 4_000_000, 360, "ref"), ("philox table traj", 4_000_000, 360, 3),
+             ("ref tree traj", 1_500_000, 1000, "ref"), ("philox table traj", 1_500_000, 1000, 3))
+    for name, n, p, stream in cases:
+        eng = S.Engine(0)
+        eng.set_table(table)
+        sim = S.Engine.make_sim(n, p, S.MODE_TABLE, 1000, stream=stream)
+        traj = torch.empty((n, p + 1), dtype=torch.float32, device=eng.tdevice)
+        final = torch.empty(n, dtype=torch.float32, device=eng.tdevice)
+
+        def run():
+            eng._enter()
+            _lib.check(eng._L.smmc_engine_simulate_keepdata(eng._h, C.byref(sim), C.c_void_p(traj.data_ptr()), C.c_void_p(final.data_ptr())))
+
+        for _ in range(3):
+            run()
+        eng.sync()
+        rounds = []
+        for _ in range(5):
+            eng.timing(True)
+            for _ in range(10):
+                run()
+            ms, k = eng.kernel_ms()
+            eng.timing(False)
+            rounds.append(ms / 10)
+        ms = sorted(rounds)[2]
+        b = 4.0 * n * (p + 1)
+        print(json.dumps({"case": name, "n_paths": n, "n_periods": p, "kernel_ms": ms, "bytes": b, "TBps": b / ms / 1e9,
+                          "frac_of_8TBps": b / ms / 1e9 / 8.0, "rounds_ms": rounds,
+                          "divide": ("fast", "exact", "checked")[eng.divide_kind(sim, keepdata=True)],
+                          "last_column_mean": float(traj[:, -1].double().mean()), "final_mean": float(final.double().mean())}), flush=True)
+        eng.close()
+
+
 def main():
     import torch
+    if len(sys.argv) > 1 and sys.argv[1] == "--traj":
+        return traj_cases()
     n360 = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
     n1000 = int(float(sys.argv[2])) if len(sys.argv) > 2 else 20_000_000
     table = load_table()
