@@ -249,15 +249,17 @@ def _lib_keepdata(eng, sim, traj):
     _lib.check(eng._L.smmc_engine_simulate_keepdata(eng._h, C.byref(sim), C.c_void_p(traj.data_ptr()), None))
 
 
-def pmc_traffic(mode, n, periods, outputs):
+def pmc_traffic(mode, n, periods, outputs, want="bytes"):
     """HBM bytes per paths_kernel launch from the rocprofv3 PMC passes committed under profiles/
     (bench.py cannot run rocprofv3 on itself): (bytes, source) or (None, None) when this workload
-    was not profiled."""
+    was not profiled.  want="valu": the entry's priced period loop (tools/valu_model.py) instead of the bytes."""
     try:
         table = json.load(open(PMC_TRAFFIC_FILE))
     except (OSError, ValueError):
         return None, None
     rec = table.get(f"{mode}|{n}|{periods}|{outputs}")
+    if not rec and want == "valu":  # the loop's price does not depend on the launch's size: any entry of the same kernel
+        rec = next((r for k, r in sorted(table.items()) if k.split("|")[0] == mode and int(k.split("|")[2]) == periods and r.get("valu")), None)
     if not rec:
         return None, None
     # the figure belongs to the build that was profiled: kernel sources + compiler flags must be the ones
@@ -269,6 +271,8 @@ def pmc_traffic(mode, n, periods, outputs):
             return None, f"stale: the kernel sources changed since {rec.get('source')}"
     except Exception as ex:
         return None, f"unverified: {ex}"
+    if want == "valu":
+        return rec.get("valu"), (rec.get("valu") or {}).get("weights_source")
     return float(rec["bytes"]), rec.get("source")
 
 
@@ -423,7 +427,7 @@ def group_child(args):
 def run_group_child(n_gpus, argv, timeout_s=None):
     """Starts `bench.py --group-child N <the run's own workload flags>` as a fresh child process (nothing here
     execs), returns its JSON object or {"error": ...}.  Never raises: the headline line must not depend on it."""
-    timeout_s = timeout_s or float(os.environ.get("SMMC_BENCH_GROUP_TIMEOUT", "300"))
+    timeout_s = timeout_s or float(os.environ.get("SMMC_BENCH_GROUP_TIMEOUT", "180"))
     keep, skip = [], 0
     for i, a in enumerate(argv):  # drop the launcher's own flags, keep the workload's
         if skip:
@@ -649,6 +653,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms, launches = eng.kernel_ms()
+    held_clock_ghz = eng.kernel_clock_ghz()  # sampled by the timed launches' own workgroups (0.0: a kernel without the probe)
     eng.timing(False)
 
     devices = [None] * world
@@ -717,6 +722,16 @@ def main():
         elif kind == 1:  # IEEE divide: not counted
             insts = None
         valu_ach = paths_per_launch * periods * insts / k_avg_s if k_avg_s > 0 and insts else 0.0
+        # the same loop priced with this round's measured issue cost of every opcode (half-rate multiplies,
+        # conversions, SDWA ...: tools/valu_model.py over profiles/r04/ubench_ops.jsonl), against the kernel's
+        # time at the clock the chip held while it ran -- sampled live by the launches' own workgroups
+        model, model_src = (pmc_traffic(mode_name, n, periods, outputs, want="valu") if args.stream == "3" and kind == 0
+                            else (None, None))
+        weighted_frac = None
+        if model and k_avg_s > 0 and held_clock_ghz > 0:
+            simds = eng.geometry()[2] * 4
+            blocks_per_simd = paths_per_launch * periods / model["periods_per_block"] / 64.0 / simds
+            weighted_frac = model["model_clk_per_block"] * blocks_per_simd / (k_avg_s * held_clock_ghz * 1e9)
         if world == 1:
             par = "single GPU"
         elif to_host:
@@ -757,8 +772,16 @@ def main():
                      # (4 bytes written per path), against the ridge point peak ops / peak bytes
                      "arithmetic_intensity": (periods * insts / 4.0) if (insts and writes_final) else None,
                      "ridge_point": VALU_PEAK_LANEOPS / (HBM_PEAK_GBS * 1e9),
-                     "note": "unweighted: every VALU instruction counted as one 2-clock issue slot; "
-                             "arithmetic_intensity in lane-ops per HBM byte"},
+                     "weighted_frac": weighted_frac,
+                     "weighted_model": ({"clk_per_block": model["model_clk_per_block"], "periods_per_block": model["periods_per_block"],
+                                         "valu_insts_per_block": model["valu_insts_per_block"], "source": model_src}
+                                        if model else None),
+                     "held_clock_ghz": held_clock_ghz or None,
+                     "held_clock_source": ("live: s_memtime / s_memrealtime of every workgroup of the timed launches "
+                                           "(smmc_engine_kernel_clock)") if held_clock_ghz else None,
+                     "note": "frac is unweighted: every VALU instruction counted as one 2-clock issue slot at the 2.4 GHz peak; "
+                             "weighted_frac prices every opcode with its measured issue cost (isolated streams) and uses "
+                             "the clock the chip held; arithmetic_intensity in lane-ops per HBM byte"},
         }
         if to_host:
             out["host_pipeline"] = {"bytes_to_host_per_step": 4.0 * n, "GBps_rank0": 4.0 * n * args.steps / dt / 1e9,

@@ -287,6 +287,12 @@ int smmc_engine_host_values_summary(smmc_engine *e, const float *host_values, ui
  * in milliseconds, and clears the log. */
 int smmc_engine_timing(smmc_engine *e, int enable);
 int smmc_engine_kernel_ms(smmc_engine *e, double *total_ms, uint32_t *launches);
+/* With timing enabled every workgroup of the path kernel also adds the shader clocks and the 100 MHz ticks of its
+ * own lifetime to two counters: *ghz = the clock the chip HELD, on average over the workgroups of the launches since
+ * the last call (0 when nothing was sampled; the reference-stream kernels are not sampled).  Synchronises and
+ * clears.  The reference's counterpart is its printed phase timers (src/simulations.cu:351-358): it has no clock
+ * read-out. */
+int smmc_engine_kernel_clock(smmc_engine *e, double *ghz);
 
 /* Device self-test of the kernels' divide shortcut over the binary32 bit patterns
  * [bits_lo, bits_hi): counts x where the reciprocal-multiply divide differs from the

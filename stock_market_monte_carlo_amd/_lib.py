@@ -108,6 +108,7 @@ SYMBOLS = [
       C.c_void_p, C.c_void_p]),
     ("smmc_engine_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("smmc_engine_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    ("smmc_engine_kernel_clock", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("smmc_engine_selftest", C.c_int,
      [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("smmc_engine_geometry", C.c_int,

@@ -118,13 +118,7 @@ struct smmc_engine {
 
   float *d_bm_tables = nullptr;  // Box-Muller radius + trig tables (Gaussian mode)
   smmc::BlockPartial *d_partials = nullptr;  // max_grid entries
-  unsigned int *d_done_count = nullptr;      // paths_kernel's finished-workgroup counter: zero between launches
-  // Small launches: workgroups of a paths_kernel variant that are resident on the whole device at once (occupancy
-  // query, cached per variant key).  A launch of fewer than kSmallLaunchRounds x that many chunks is capped at the
-  // resident count: every workgroup then stages its draw tables once and strides over its chunks.
-  std::vector<std::pair<uint64_t, uint32_t>> resident_cache;
-  uint32_t small_launch_rounds = 8;          // SMMC_SMALL_LAUNCH_ROUNDS (0: never cap)
-  bool finalize_launch = false;              // SMMC_FINALIZE=launch: round 3's separate finalize_kernel (test knob: same bits)
+  unsigned long long *d_clock = nullptr;     // timing: [shader clocks, 100 MHz ticks] summed over paths_kernel's workgroups
 
   // simulate_to_host staging
   float *d_stage[2] = {nullptr, nullptr};
@@ -411,6 +405,20 @@ int enqueue_ref_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, fl
       a.n_paths = static_cast<uint32_t>(count);
       a.d_final = fin + first;
       a.d_traj = d_traj ? d_traj + first * (static_cast<uint64_t>(P) + 1) : nullptr;
+      // trajectories: consecutive rows per lane.  More rows are fewer junction lines and fewer, longer work units:
+      // the largest of 8 / 4 / 2 / 1 that still makes one and a half rounds of the resident workgroups (four per CU:
+      // the tiles' LDS).  Measured (profiles/r04/bench_ref_traj.jsonl): 4e6 x 361 values K = 8 / 4 / 2 / 1 1.78 / 1.98 /
+      // 2.11 / 2.18 ms (1953 units at K = 8); 1.5e6 x 1001 3.21 / 2.99 / 2.75 / 2.82 ms (733 units at K = 8: the chip
+      // is not filled).  SMMC_REF_TRAJ_ROWS forces one; results do not depend on it.
+      a.traj_rows = 8;
+      if (d_traj) {
+        const uint64_t n_super = (count + 2047) / 2048, want = 6ull * e->compute_units;
+        while (a.traj_rows > 1 && n_super * (8u / a.traj_rows) < want) a.traj_rows /= 2;
+        if (const char *env = std::getenv("SMMC_REF_TRAJ_ROWS")) {  // tuning knob
+          const long v = std::strtol(env, nullptr, 10);
+          if (v == 8 || v == 4 || v == 2 || v == 1) a.traj_rows = static_cast<uint32_t>(v);
+        }
+      }
       const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((count + smmc::kBlock - 1) / smmc::kBlock, e->max_grid));
       if (windowed) {
         a.redo_count = e->d_ref_redo;
@@ -447,44 +455,18 @@ int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float 
   a.d_chunk_mean = d_chunk_mean;
   a.d_chunk_var = d_chunk_var;
   const uint64_t n_chunks = (s->n_paths + smmc::kBlock - 1) / smmc::kBlock;
-  uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid));
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid));
   if (d_stats) {
     SMMC_HIP(hipMemsetAsync(d_stats, 0, smmc_stats_bytes(s->n_bins), e->stream));
     a.partials = e->d_partials;
     a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
-    // the workgroup that finishes last folds the partials into the header (no finalize launch)
-    if (!e->finalize_launch) {
-      a.d_stats_out = static_cast<smmc_stats *>(d_stats);
-      a.done_count = e->d_done_count;
-    }
   }
+  a.clock_probe = e->timing ? e->d_clock : nullptr;
   if (grid > 0) {
     const size_t lds = smmc::paths_lds_bytes(a.table_len, d_stats ? s->n_bins : 0u, a.stream);
     if (lds + 2048 > e->max_lds)
       return fail(SMMC_ERR_INVALID, "table + histogram need %zu bytes of LDS, device allows %zu", lds, e->max_lds);
     const int div = divide_kind(e, s, true, &a.chk_lo, &a.chk_hi);
-    if (e->small_launch_rounds) {
-      // A launch of a few rounds of workgroups (BASELINE configs[0]: 3907 chunks, 1024 resident in Gaussian mode)
-      // gains nothing from queued workgroups -- there is no long tail to even out -- and pays the staging of
-      // the draw tables (24 KiB in Gaussian mode) once per chunk: cap it at what is resident.
-      const uint64_t key = (static_cast<uint64_t>(lds) << 16) | (static_cast<uint64_t>(a.stream & 3) << 12) |
-                           (static_cast<uint64_t>(a.mode & 3) << 8) | (static_cast<uint64_t>(a.table_len > 2048u) << 4) |
-                           static_cast<uint64_t>(div & 3);
-      uint32_t per_cu = 0;
-      bool known = false;
-      for (const auto &kv : e->resident_cache)
-        if (kv.first == key) {
-          per_cu = kv.second;
-          known = true;
-        }
-      if (!known) {
-        per_cu = smmc::paths_resident_per_cu(a, div, lds);
-        e->resident_cache.emplace_back(key, per_cu);
-      }
-      const uint64_t resident = static_cast<uint64_t>(per_cu) * e->compute_units;
-      if (resident && n_chunks > resident && n_chunks < resident * e->small_launch_rounds)
-        grid = static_cast<uint32_t>(std::min<uint64_t>(resident, grid));
-    }
     int rc = timing_begin(e);
     if (rc) return rc;
     const hipError_t err = smmc::launch_paths(a, div, grid, lds, e->stream);
@@ -495,7 +477,7 @@ int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float 
     rc = timing_end(e);
     if (rc) return rc;
   }
-  if (d_stats && (grid == 0 || e->finalize_launch))  // no path at all (the record of an empty run), or the test knob
+  if (d_stats)
     SMMC_HIP(smmc::launch_finalize(e->d_partials, grid, static_cast<smmc_stats *>(d_stats), s->n_bins, e->stream));
   return SMMC_OK;
 }
@@ -578,11 +560,6 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     else if (v >= smmc::kBlock) e->host_chunk_paths = static_cast<uint64_t>(v) / smmc::kBlock * smmc::kBlock;  // tests
   }
   e->pin_policy = smmc::pin_policy_from_env();  // SMMC_PIN_HOST: see smmc_engine_simulate_to_host, smmc_host.h
-  if (const char *env = std::getenv("SMMC_FINALIZE")) e->finalize_launch = !std::strcmp(env, "launch");  // test knob, same bits
-  if (const char *env = std::getenv("SMMC_SMALL_LAUNCH_ROUNDS")) {  // tuning knob; the per-path results do not depend on it
-    const long v = std::strtol(env, nullptr, 10);
-    if (v >= 0 && v <= 1024) e->small_launch_rounds = static_cast<uint32_t>(v);
-  }
   if (const char *env = std::getenv("SMMC_REF_KERNEL")) {  // test knob, results do not depend on it
     e->ref_kernel = !std::strcmp(env, "windowed") ? 1 : !std::strcmp(env, "generic") ? 2 : 0;
   }
@@ -632,8 +609,6 @@ int smmc_engine_create(int device, void *stream, smmc_engine **out) {
     err_tables = hipSetDevice(device);
     if (err_tables == hipSuccess)
       err_tables = hipMalloc(reinterpret_cast<void **>(&e->d_partials), sizeof(smmc::BlockPartial) * e->max_grid);
-    if (err_tables == hipSuccess) err_tables = hipMalloc(reinterpret_cast<void **>(&e->d_done_count), sizeof(unsigned int));
-    if (err_tables == hipSuccess) err_tables = hipMemset(e->d_done_count, 0, sizeof(unsigned int));
     // the Gaussian kernels read counter stream v3's tables at absolute LDS addresses from 0
     if (err_tables == hipSuccess) err_tables = smmc::static_lds_bytes(&static_lds);
     phase.mark("kernel attributes (code object loaded)");
@@ -697,7 +672,7 @@ void smmc_engine_destroy(smmc_engine *e) {
   if (e->d_ref_redo) (void)hipFree(e->d_ref_redo);
   if (e->d_ref_ws) (void)hipFree(e->d_ref_ws);
   if (e->d_partials) (void)hipFree(e->d_partials);
-  if (e->d_done_count) (void)hipFree(e->d_done_count);
+  if (e->d_clock) (void)hipFree(e->d_clock);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1446,7 +1421,27 @@ int smmc_engine_set_progress(smmc_engine *e, smmc_progress_fn fn, void *user) {
 
 int smmc_engine_timing(smmc_engine *e, int enable) {
   if (!e) return fail(SMMC_ERR_INVALID, "engine is NULL");
+  if (enable && !e->d_clock) {
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_clock), 2 * sizeof(unsigned long long)));
+    SMMC_HIP(hipMemsetAsync(e->d_clock, 0, 2 * sizeof(unsigned long long), e->stream));
+  }
   e->timing = enable != 0;
+  return SMMC_OK;
+}
+
+int smmc_engine_kernel_clock(smmc_engine *e, double *ghz) {
+  if (!e || !ghz) return fail(SMMC_ERR_INVALID, "NULL argument");
+  *ghz = 0.0;
+  if (!e->d_clock) return SMMC_OK;  // timing was never enabled
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+  unsigned long long h[2] = {0, 0};
+  SMMC_HIP(hipMemcpyAsync(h, e->d_clock, sizeof h, hipMemcpyDeviceToHost, e->stream));
+  SMMC_HIP(hipMemsetAsync(e->d_clock, 0, sizeof h, e->stream));
+  SMMC_HIP(hipStreamSynchronize(e->stream));
+  if (h[1]) *ghz = static_cast<double>(h[0]) / static_cast<double>(h[1]) * 0.1;  // s_memrealtime ticks at 100 MHz
   return SMMC_OK;
 }
 

@@ -54,6 +54,16 @@ __device__ __forceinline__ T lds_load_at(uint32_t byte_addr) {
   return *reinterpret_cast<const __attribute__((address_space(3))) T *>(static_cast<uintptr_t>(byte_addr));
 }
 
+// A wave-uniform constant as a VGPR operand.  In a stream of its own a VALU instruction with an SGPR source issues
+// at half rate on gfx950 (v_bitop3_b32 2.3 clk per wave with three VGPRs, 4.1 with a scalar; tools/ubench_ops.hip);
+// in the kernels' mixes the scalar operand is a port that is rarely full, and holding the constants of the
+// three-input logic operations in VGPRs (VOP3 takes no literals; the compiler puts every uniform value into an SGPR)
+// is worth 0.2-0.8 % (profiles/r04/ab_operands.txt, ab_table.txt) -- kept because it is free.
+__device__ __forceinline__ uint32_t vgpr_const(uint32_t c) {
+  asm("" : "+v"(c));
+  return c;
+}
+
 // kDiv: how total * a / 100 is formed.  kDivFast: the reciprocal-multiply form, the host has proven
 // that no product of any path leaves its domain.  kDivExact: the IEEE divide.  kDivChecked: the
 // fast form while the path stays inside a window [chk_lo, chk_hi] tested once per Philox block --

@@ -40,11 +40,10 @@ struct KernelArgs {
   float below_threshold;
   float *d_traj;         // keepdata only: n_paths x (n_periods + 1), path-major
   float chk_lo, chk_hi;  // SMMC_DIV_CHECKED only: the window a path must stay in at Philox-block boundaries
-  // paths_kernel with statistics: the workgroup that finishes LAST folds the partials into the record's header
-  // itself (no finalize launch).  *done_count counts finished workgroups; it is zero before a launch and the
-  // folding workgroup leaves it zero again.
-  smmc_stats *d_stats_out;   // nullable: partials are then left to finalize_kernel
-  unsigned int *done_count;
+  // Timing instrumentation (smmc_engine_timing): every workgroup of paths_kernel adds the shader clocks
+  // (s_memtime) and the 100 MHz ticks (s_memrealtime) of its own lifetime -- their ratio is the clock the chip
+  // HELD while this launch ran (smmc_engine_kernel_clock).  nullable.
+  unsigned long long *clock_probe;
 };
 
 // The reference's own stream (SMMC_FLAG_STREAM_REF, smmc_ref_kernels.hip): per-path mt19937 seeded with
@@ -60,6 +59,7 @@ struct RefArgs {
   float chk_lo, chk_hi;   // SMMC_DIV_CHECKED: as KernelArgs
   float *d_final;         // n_paths floats
   float *d_traj;          // nullable: n_paths rows of n_periods + 1 floats (keepdata)
+  uint32_t traj_rows;     // d_traj, state-free kernels: consecutive rows per lane (8, 4, 2 or 1: TrajWriter, smmc_ref_kernels.hip)
   uint32_t *redo_count;   // windowed kernel: paths it left unfinished (appended to redo_list); generic kernel
   uint32_t *redo_list;    //   with redo_list != nullptr: the work items are redo_list[0 .. *redo_count)
   uint32_t *workspace;    // generic kernel: ref_workspace_bytes(grid)
@@ -120,8 +120,6 @@ hipError_t launch_radix_pick(int pass, uint32_t n_ranks, SelectState *st, const 
 // `div`: SMMC_DIV_* of smmc.h (how a launch divides by 100: simulate_path in smmc_kernels.hip)
 hipError_t launch_paths(const KernelArgs &a, int div, uint32_t grid, size_t lds_bytes,
                         hipStream_t stream);
-// workgroups of that paths_kernel variant a compute unit holds at once (occupancy query; 0 on error)
-uint32_t paths_resident_per_cu(const KernelArgs &a, int div, size_t lds_bytes);
 hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, smmc_stats *d_stats,
                            uint32_t n_bins, hipStream_t stream, const unsigned long long *hist_spread = nullptr,
                            uint32_t spread = 0);

@@ -40,9 +40,38 @@ constexpr uint32_t kDenseMaxTable = 2048u;  // largest table drawn eight-per-blo
 //            otherwise re-associates it apart: an instruction reads at most one SGPR, so a v_bitop3
 //            with two scalar terms costs a v_mov); round 2's first XOR likewise.
 // With the counter (path, block, mode) of stream v2 the same rounds cost four (one multiply among them).
+// Issue rates on gfx950 (tools/ubench_ops.hip, profiles/r04/ubench_ops.jsonl): a VALU instruction that reads an
+// SGPR operand issues at HALF rate (v_xor_b32 2.1 clk per wave with VGPR or literal operands, 4.1 with one
+// SGPR; v_mul_f32, v_add_u32 the same), and v_bitop3_b32 takes 2.7 clk with three VGPRs against 4.1 with a
+// scalar round key.  The wave-uniform constants the period loops read in every block -- the Philox round keys
+// of the three-input XORs, the Gaussian draw's additive term -- are therefore held in VGPRs (made opaque to
+// the compiler, which would otherwise put every uniform value into an SGPR): 16 + 1 registers per lane, set
+// up once per kernel.  Values that change from block to block (the scalarised first rounds) stay scalar: a
+// v_mov into a VGPR costs what the SGPR operand costs.
+struct DrawRegs {
+  uint32_t k0[10], k1[10];  // Philox round keys key + r * Weyl, as VGPRs
+  float shift100;           // 100.0f + gauss_mean
+};
+__device__ __forceinline__ DrawRegs make_draw_regs(const KernelArgs &k) {
+  DrawRegs d;
+  uint32_t a = k.key0, b = k.key1;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    d.k0[r] = a;
+    d.k1[r] = b;
+    asm("" : "+v"(d.k0[r]));  // not volatile: set up once, outside the loops; unused ones disappear
+    asm("" : "+v"(d.k1[r]));
+    a += kWeyl0;
+    b += kWeyl1;
+  }
+  d.shift100 = k.gauss_shift100;
+  asm("" : "+v"(d.shift100));
+  return d;
+}
+
 template <bool kUniformFirst = false>
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+                                              uint32_t k0, uint32_t k1, const DrawRegs &dr, uint32_t (&out)[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = static_cast<uint64_t>(kPhiloxM0) * c0;
@@ -59,13 +88,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
       uint32_t pair0 = c1 ^ k0;
       asm("" : "+s"(pair0));
       n0 = pair0 ^ h1;
-      n2 = xor3(h0, c3, k1);
+      n2 = xor3(h0, c3, dr.k1[r]);
     } else if (r < 2) {  // plain XORs: invariant and scalar parts are the compiler's to hoist and to scalarise
       n0 = (h1 ^ k0) ^ c1;
       n2 = (h0 ^ k1) ^ c3;
     } else {
-      n0 = xor3(h1, c1, k0);
-      n2 = xor3(h0, c3, k1);
+      n0 = xor3(h1, c1, dr.k0[r]);
+      n2 = xor3(h0, c3, dr.k1[r]);
     }
     c1 = static_cast<uint32_t>(p1);
     c3 = static_cast<uint32_t>(p0);
@@ -86,7 +115,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // A wave alone can issue a dependent VALU instruction only every 4-8 cycles; below ~6 waves per SIMD
 // this instruction-level parallelism is what fills the issue slots.
 template <int N, bool kUniformFirst = false>
-__device__ __forceinline__ void philox4x32_10_multi(uint32_t (&c)[N][4], uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ void philox4x32_10_multi(uint32_t (&c)[N][4], uint32_t k0, uint32_t k1, const DrawRegs &dr) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     uint64_t p0[N], p1[N];
@@ -109,13 +138,13 @@ __device__ __forceinline__ void philox4x32_10_multi(uint32_t (&c)[N][4], uint32_
         uint32_t pair0 = c[i][1] ^ k0;
         asm("" : "+s"(pair0));
         n0 = pair0 ^ h1;
-        n2 = xor3(h0, c[i][3], k1);
+        n2 = xor3(h0, c[i][3], dr.k1[r]);
       } else if (r < 2) {
         n0 = (h1 ^ k0) ^ c[i][1];
         n2 = (h0 ^ k1) ^ c[i][3];
       } else {
-        n0 = xor3(h1, c[i][1], k0);
-        n2 = xor3(h0, c[i][3], k1);
+        n0 = xor3(h1, c[i][1], dr.k0[r]);
+        n2 = xor3(h0, c[i][3], dr.k1[r]);
       }
       c[i][1] = static_cast<uint32_t>(p1[i]);
       c[i][3] = static_cast<uint32_t>(p0[i]);
@@ -314,14 +343,14 @@ __device__ __forceinline__ void digits4(uint32_t h, uint32_t l, uint32_t T, uint
 
 // The per-period multipliers a = 100.0f + r of Philox block `blk` of a path.
 template <int kMode, bool kDense, bool kUniformBlock = false>
-__device__ __forceinline__ void block_multipliers(const KernelArgs &k, const float *lds_table,
+__device__ __forceinline__ void block_multipliers(const KernelArgs &k, const DrawRegs &dr, const float *lds_table,
                                                   uint32_t path_lo, uint32_t path_hi, uint32_t blk,
                                                   float (&a)[Draws<kMode, kDense>::value]) {
   uint32_t u[4];
   if constexpr (counter_v3(kMode))
-    philox4x32_10<kUniformBlock>(blk, path_lo, path_hi, mode_tag(kMode), k.key0, k.key1, u);
+    philox4x32_10<kUniformBlock>(blk, path_lo, path_hi, mode_tag(kMode), k.key0, k.key1, dr, u);
   else
-    philox4x32_10<false>(path_lo, path_hi, blk, mode_tag(kMode), k.key0, k.key1, u);
+    philox4x32_10<false>(path_lo, path_hi, blk, mode_tag(kMode), k.key0, k.key1, dr, u);
   if constexpr (is_table(kMode) && kDense) {
     uint32_t ia[4], ib[4];
     digits4(u[0], u[1], k.table_len, ia);
@@ -343,8 +372,8 @@ __device__ __forceinline__ void block_multipliers(const KernelArgs &k, const flo
   } else {  // counter stream v3: the multipliers themselves, N(100 + gauss_mean, gauss_std)
     const Bm3Pending p0 = bm3_issue(lds_table, u[0], u[1]);
     const Bm3Pending p1 = bm3_issue(lds_table, u[2], u[3]);
-    bm3_finish(p0, k.gauss_shift100, a[0], a[1]);
-    bm3_finish(p1, k.gauss_shift100, a[2], a[3]);
+    bm3_finish(p0, dr.shift100, a[0], a[1]);
+    bm3_finish(p1, dr.shift100, a[2], a[3]);
   }
 }
 
@@ -352,7 +381,7 @@ __device__ __forceinline__ void block_multipliers(const KernelArgs &k, const flo
 // interleaved Philox rounds, then all table gathers issued before the first is used.  The values are
 // those of N calls of block_multipliers.
 template <int kMode, bool kDense, int N, bool kUniformBlock = false>
-__device__ __forceinline__ void block_multipliers_multi(const KernelArgs &k, const float *lds_table, uint32_t path_lo,
+__device__ __forceinline__ void block_multipliers_multi(const KernelArgs &k, const DrawRegs &dr, const float *lds_table, uint32_t path_lo,
                                                         uint32_t path_hi, uint32_t blk,
                                                         float (&a)[N][Draws<kMode, kDense>::value]) {
   uint32_t u[N][4];
@@ -363,7 +392,7 @@ __device__ __forceinline__ void block_multipliers_multi(const KernelArgs &k, con
     u[i][2] = counter_v3(kMode) ? path_hi : blk + i;
     u[i][3] = mode_tag(kMode);
   }
-  philox4x32_10_multi<N, kUniformBlock && counter_v3(kMode)>(u, k.key0, k.key1);
+  philox4x32_10_multi<N, kUniformBlock && counter_v3(kMode)>(u, k.key0, k.key1, dr);
   if constexpr (is_table(kMode) && kDense) {
     uint32_t idx[N][8];
 #pragma unroll
@@ -410,14 +439,14 @@ __device__ __forceinline__ void block_multipliers_multi(const KernelArgs &k, con
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      bm3_finish(p[i][0], k.gauss_shift100, a[i][0], a[i][1]);
-      bm3_finish(p[i][1], k.gauss_shift100, a[i][2], a[i][3]);
+      bm3_finish(p[i][0], dr.shift100, a[i][0], a[i][1]);
+      bm3_finish(p[i][1], dr.shift100, a[i][2], a[i][3]);
     }
   }
 }
 
 template <int kMode, int kDiv, bool kDense>
-__device__ __forceinline__ float simulate_path(const KernelArgs &k, const float *lds_table,
+__device__ __forceinline__ float simulate_path(const KernelArgs &k, const DrawRegs &dr, const float *lds_table,
                                                uint64_t path) {
   constexpr int kDraws = Draws<kMode, kDense>::value;
   constexpr bool kExactDiv = kDiv == kDivExact;
@@ -433,7 +462,7 @@ __device__ __forceinline__ float simulate_path(const KernelArgs &k, const float 
   // front of this block's chain.)
   for (uint32_t blk = 0; blk < full; ++blk) {
     float a[kDraws];
-    block_multipliers<kMode, kDense, true>(k, lds_table, path_lo, path_hi, blk, a);
+    block_multipliers<kMode, kDense, true>(k, dr, lds_table, path_lo, path_hi, blk, a);
 #pragma unroll
     for (int j = 0; j < kDraws; ++j) total = compound<kExactDiv>(total, a[j]);
     if constexpr (kDiv == kDivChecked) left_window |= !(total > k.chk_lo && total < k.chk_hi);  // NaN leaves too
@@ -441,28 +470,29 @@ __device__ __forceinline__ float simulate_path(const KernelArgs &k, const float 
   const uint32_t rem = k.n_periods - full * kDraws;
   if (rem) {  // wave-uniform
     float a[kDraws];
-    block_multipliers<kMode, kDense, true>(k, lds_table, path_lo, path_hi, full, a);
+    block_multipliers<kMode, kDense, true>(k, dr, lds_table, path_lo, path_hi, full, a);
 #pragma unroll
     for (int j = 0; j < kDraws - 1; ++j)
       if (static_cast<uint32_t>(j) < rem) total = compound<kExactDiv>(total, a[j]);
   }
   if constexpr (kDiv == kDivChecked) {
-    if (left_window) total = simulate_path<kMode, kDivExact, kDense>(k, lds_table, path);
+    if (left_window) total = simulate_path<kMode, kDivExact, kDense>(k, dr, lds_table, path);
   }
   return total;
 }
 
-// ---- folding the workgroups' partial statistics -----------------------------------------------
+// ---- the workgroups' partial statistics ----------------------------------------------------------
 //
-// One order for every launch shape, so that the double sums of a given grid never depend on which kernel
-// folds them: kFoldWidth accumulators, accumulator v takes partials v, v + kFoldWidth, ... in ascending
-// order, then a binary tree over the accumulators (v += v + s for s = kFoldWidth / 2 ... 1).
-// finalize_kernel runs it with one thread per accumulator; the last workgroup of paths_kernel (256
-// threads) gives every thread the four accumulators t, t + 256, t + 512, t + 768 -- the tree's first two
-// levels then stay inside a thread -- and finishes the tree through LDS.  Same additions, same order,
-// same bits.
-constexpr int kFoldWidth = 1024;
-
+// paths_kernel leaves one partial per workgroup; finalize_kernel (one 1024-thread workgroup, a launch later) folds them
+// in a fixed order.  Round 4 tried to fold them INSIDE the launch (the workgroup that finishes last
+// writes the header) in three forms, all bit-identical to the separate launch and all measured on the 1e6-path step
+// (profiles/r04/config0_variants*.txt; the separate launch: 169.5 us per step, kernel 159 us): a release fence per
+// workgroup + one arrival counter 178-265 us (the fence waits for every final value queued in the XCD's L2; same-address
+// atomics take ~12 ns each); device-scope atomic exchanges instead of the fence + 64 + 1 counters, the last workgroup
+// folding all 3907 partials 180.6 us (15 dependent rounds of device-scope loads per thread); a two-level fold -- the
+// workgroup that completes a group of 64 folds it, the one that completes the groups folds those -- 172.5 us.  The
+// floor is the chain itself: publish, count, load, publish, count, load are six device-scope round trips of ~1.7 us
+// across the eight XCDs, as long as the launch boundary they replace.  The separate launch stays.
 __device__ __forceinline__ void partial_identity(BlockPartial &t) {
   t.sum = 0.0;
   t.sumsq = 0.0;
@@ -479,39 +509,6 @@ __device__ __forceinline__ void partial_add(BlockPartial &a, const BlockPartial 
   a.overflow += b.overflow;
   a.min = fminf(a.min, b.min);
   a.max = fmaxf(a.max, b.max);
-}
-__device__ __forceinline__ void write_header(smmc_stats *out, const BlockPartial &r, uint32_t n_bins) {
-  out->count = r.count;
-  out->below = r.below;
-  out->underflow = r.underflow;
-  out->overflow = r.overflow;
-  out->sum = r.sum;
-  out->sumsq = r.sumsq;
-  out->min = r.min;
-  out->max = r.max;
-  out->n_bins = n_bins;
-  out->reserved = 0;
-}
-
-// The fold by ONE workgroup of kBlock threads; `sh` is kBlock BlockPartials of LDS.  Thread 0 returns the total.
-__device__ __forceinline__ BlockPartial fold_partials_block(const BlockPartial *partials, uint32_t n_partials, BlockPartial *sh) {
-  static_assert(kFoldWidth == 4 * kBlock, "a thread carries four accumulators");
-  BlockPartial acc[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    partial_identity(acc[q]);
-    for (uint32_t j = threadIdx.x + q * kBlock; j < n_partials; j += kFoldWidth) partial_add(acc[q], partials[j]);
-  }
-  partial_add(acc[0], acc[2]);  // tree level s = 512: v += v + 512
-  partial_add(acc[1], acc[3]);
-  partial_add(acc[0], acc[1]);  // s = 256
-  sh[threadIdx.x] = acc[0];
-  __syncthreads();
-  for (uint32_t s = kBlock / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) partial_add(sh[threadIdx.x], sh[threadIdx.x + s]);
-    __syncthreads();
-  }
-  return sh[0];
 }
 
 // ---- main kernel ---------------------------------------------------------------
@@ -534,6 +531,11 @@ __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
 
   const uint32_t tid = threadIdx.x;
   bool parity = false;
+  unsigned long long clk0 = 0, real0 = 0;
+  if (k.clock_probe) {  // uniform; timing instrumentation only
+    clk0 = __builtin_amdgcn_s_memtime();
+    real0 = __builtin_amdgcn_s_memrealtime();
+  }
   stage_tables<kMode>(k, lds_table);
   const bool want_stats = k.partials != nullptr;
   const bool want_hist = want_stats && k.n_bins != 0;
@@ -545,6 +547,7 @@ __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
   double sum = 0.0, sumsq = 0.0;
   uint32_t n_count = 0, n_below = 0, n_under = 0, n_over = 0;
   float vmin = __builtin_inff(), vmax = -__builtin_inff();
+  const DrawRegs dr = make_draw_regs(k);
 
   const uint64_t n_chunks = (k.n_paths + kBlock - 1) / kBlock;
   for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
     const bool active = i < k.n_paths;
     float v = 0.0f;
     if (active) {
-      v = simulate_path<kMode, kDiv, kDense>(k, lds_table, k.first_path + i);
+      v = simulate_path<kMode, kDiv, kDense>(k, dr, lds_table, k.first_path + i);
       if (k.d_final) k.d_final[i] = v;
     }
     if (want_stats && active) {
@@ -606,6 +609,10 @@ __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
     }
   }
 
+  if (k.clock_probe && tid == 0) {
+    atomicAdd(&k.clock_probe[0], __builtin_amdgcn_s_memtime() - clk0);
+    atomicAdd(&k.clock_probe[1], __builtin_amdgcn_s_memrealtime() - real0);
+  }
   if (want_stats) {
     // per-lane u32 counters cannot overflow: a lane sees < 2^32 chunks
     BlockPartial p;
@@ -641,34 +648,6 @@ __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
         if (c) atomicAdd(&k.d_hist[b], static_cast<unsigned long long>(c));
       }
     }
-    if (k.d_stats_out) {
-      // The workgroup that finishes last writes the record's header (round 3 launched finalize_kernel for
-      // that: a dependent launch boundary, 11 us of a 187 us step at 1e6 paths).  Release: this workgroup's
-      // partial is visible device-wide (the fence writes it back past this XCD's L2) before its count is;
-      // acquire: the last one sees every other workgroup's.  The fold's order is finalize_kernel's.
-      // (the flag lives in the reduction scratch, not in a static __shared__ word: the Gaussian kernels must have
-      // no static LDS, their draw tables sit at LDS address 0)
-      volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(red_scratch);
-      if (tid == 0) {
-        __threadfence();
-        const uint32_t done = __hip_atomic_fetch_add(k.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = done + 1u == gridDim.x ? 1u : 0u;
-      }
-      __syncthreads();
-      const bool is_last = *flag != 0u;  // workgroup-uniform
-      __syncthreads();                   // every thread has read the flag: the fold may overwrite it
-      if (is_last) {
-        __threadfence();
-        // kBlock BlockPartials (14 KiB: paths_lds_bytes reserves them) at the front of the dynamic allocation:
-        // the draw tables and the histogram are not read any more
-        BlockPartial *sh = reinterpret_cast<BlockPartial *>(lds_raw);
-        const BlockPartial total = fold_partials_block(k.partials, gridDim.x, sh);
-        if (tid == 0) {
-          write_header(k.d_stats_out, total, k.n_bins);
-          __hip_atomic_store(k.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        }
-      }
-    }
   }
 }
 
@@ -688,7 +667,6 @@ __global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const BlockPar
     }
   }
   __shared__ BlockPartial sh[kFinalizeBlock];
-  static_assert(kFinalizeBlock == kFoldWidth, "one thread per accumulator of the fold");
   BlockPartial t;
   partial_identity(t);
   for (uint32_t j = threadIdx.x; j < n_partials; j += kFinalizeBlock) partial_add(t, partials[j]);
@@ -698,7 +676,19 @@ __global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const BlockPar
     if (threadIdx.x < s) partial_add(sh[threadIdx.x], sh[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) write_header(out, sh[0], n_bins);
+  if (threadIdx.x == 0) {
+    const BlockPartial &r = sh[0];
+    out->count = r.count;
+    out->below = r.below;
+    out->underflow = r.underflow;
+    out->overflow = r.overflow;
+    out->sum = r.sum;
+    out->sumsq = r.sumsq;
+    out->min = r.min;
+    out->max = r.max;
+    out->n_bins = n_bins;
+    out->reserved = 0;
+  }
 }
 
 // ---- keepdata: every trajectory, path-major ------------------------------------
@@ -785,6 +775,7 @@ __global__ __launch_bounds__(kKeepdataMaxBlock) void keepdata_kernel(const Kerne
   float *my_trash = lds_table + table_words + n_waves * (64 * kRowMax) + tid;
   stage_tables<kMode>(k, lds_table, blockDim.x);
   __syncthreads();
+  const DrawRegs dr = make_draw_regs(k);
 
   const uint32_t sub = lane / kQuads, quad = lane % kQuads;  // store phase: row sub + kRowsPerStore it, columns 4 quad .. + 3
   const uint32_t n_periods = k.n_periods;
@@ -868,7 +859,7 @@ __global__ __launch_bounds__(kKeepdataMaxBlock) void keepdata_kernel(const Kerne
 #pragma unroll
         for (uint32_t cb = 0; cb < kTile; cb += kDraws) {
           float a[kDraws];
-          block_multipliers<kMode, kDense>(k, lds_table, path_lo, path_hi, grp0 + cb / kDraws - q, a);
+          block_multipliers<kMode, kDense>(k, dr, lds_table, path_lo, path_hi, grp0 + cb / kDraws - q, a);
 #pragma unroll
           for (int j = 0; j < kDraws; ++j) {
             total = compound<kExactDiv>(total, a[j]);
@@ -881,7 +872,7 @@ __global__ __launch_bounds__(kKeepdataMaxBlock) void keepdata_kernel(const Kerne
         if (g0 + cb > last_col) break;  // uniform: nothing to draw beyond
         const uint32_t grp = (g0 + cb) / kDraws;
         float a[kDraws];
-        block_multipliers<kMode, kDense>(k, lds_table, path_lo, path_hi, grp - q, a);
+        block_multipliers<kMode, kDense>(k, dr, lds_table, path_lo, path_hi, grp - q, a);
         if (grp >= kGroupsPerTile && grp < tail_start) {  // uniform: every lane is inside its own row
           float *dst = wr + cb;
 #pragma unroll
@@ -1033,6 +1024,7 @@ __global__ __launch_bounds__(kCombMaxBlock) void keepdata_comb_kernel(const Kern
   float *tile = lds_table + table_words + wave * comb_tile_words(kDraws);
   stage_tables<kMode>(k, lds_table, blockDim.x);
   __syncthreads();
+  const DrawRegs dr = make_draw_regs(k);
 
   const uint32_t K = rows_per_stream, waves_per_super = 32u / K;
   const uint32_t n_periods = k.n_periods, row_len = n_periods + 1u, n_blocks = n_periods / kDraws;
@@ -1136,7 +1128,7 @@ __global__ __launch_bounds__(kCombMaxBlock) void keepdata_comb_kernel(const Kern
       // their compounding chains follow one after the other.  The host guarantees that a row is a
       // whole number of steps.
       float a[kBlocksPerStep][kDraws];
-      block_multipliers_multi<kMode, kDense, kBlocksPerStep, true>(k, lds_table, path_lo, path_hi, blk, a);
+      block_multipliers_multi<kMode, kDense, kBlocksPerStep, true>(k, dr, lds_table, path_lo, path_hi, blk, a);
 #pragma unroll
       for (int b = 0; b < kBlocksPerStep; ++b) {
         if (done) break;
@@ -1205,9 +1197,7 @@ static size_t draw_table_words(uint32_t table_len, int stream) {
 size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins, int stream) {
   // [draw tables][histogram][pad to 8 bytes][red_scratch: 4 kWaves doubles][wave_part: kWaves BlockPartial]
   const size_t words = (draw_table_words(table_len, stream) + n_bins + 1u) & ~static_cast<size_t>(1);
-  const size_t bytes = words * 4u + 4u * kWaves * sizeof(double) + kWaves * sizeof(BlockPartial);
-  // ... or, for the workgroup that folds the partials at the end of a launch, kBlock BlockPartials from the front
-  return bytes > kBlock * sizeof(BlockPartial) ? bytes : kBlock * sizeof(BlockPartial);
+  return words * 4u + 4u * kWaves * sizeof(double) + kWaves * sizeof(BlockPartial);
 }
 bool table_is_dense(uint32_t table_len);
 // keepdata_kernel: tables + per wave 64 rows of (tile 16 | 32 columns + kDraws more slots, at the
@@ -1272,30 +1262,6 @@ static hipError_t launch_paths_mode(const KernelArgs &a, int div, uint32_t grid,
 }
 
 bool table_is_dense(uint32_t table_len) { return table_len <= kDenseMaxTable; }
-
-template <int kMode, bool kDense>
-static uint32_t resident_paths_mode(int div, size_t lds) {
-  int n = 0;
-  hipError_t err;
-  switch (div) {
-    case SMMC_DIV_FAST: err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, paths_kernel<kMode, kDivFast, kDense>, kBlock, lds); break;
-    case SMMC_DIV_CHECKED: err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, paths_kernel<kMode, kDivChecked, kDense>, kBlock, lds); break;
-    default: err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, paths_kernel<kMode, kDivExact, kDense>, kBlock, lds); break;
-  }
-  if (err != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
-  }
-  return n > 0 ? static_cast<uint32_t>(n) : 0u;
-}
-
-uint32_t paths_resident_per_cu(const KernelArgs &a, int div, size_t lds_bytes) {
-  if (a.mode != SMMC_MODE_TABLE)
-    return a.stream == 2 ? resident_paths_mode<kModeGaussianV2, false>(div, lds_bytes) : resident_paths_mode<SMMC_MODE_GAUSSIAN, false>(div, lds_bytes);
-  if (a.stream == 2)
-    return table_is_dense(a.table_len) ? resident_paths_mode<kModeTableV2, true>(div, lds_bytes) : resident_paths_mode<kModeTableV2, false>(div, lds_bytes);
-  return table_is_dense(a.table_len) ? resident_paths_mode<SMMC_MODE_TABLE, true>(div, lds_bytes) : resident_paths_mode<SMMC_MODE_TABLE, false>(div, lds_bytes);
-}
 
 hipError_t launch_paths(const KernelArgs &a, int div, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
   if (a.mode != SMMC_MODE_TABLE)

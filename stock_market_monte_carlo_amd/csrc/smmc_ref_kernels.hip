@@ -86,23 +86,36 @@ __device__ __forceinline__ uint32_t mt_run_up(uint32_t seed, uint32_t k) {
   return x;
 }
 
+// The three masks of the twist and the tempering, as VGPR operands of their v_bitop3_b32 (vgpr_const, smmc_device.h):
+// set up once per kernel beside the multiplier.
+struct MtConsts {
+  uint32_t magic, temper_b, temper_c;
+};
+__device__ __forceinline__ MtConsts mt_consts() {
+  MtConsts c;
+  c.magic = vgpr_const(0x9908b0dfu);
+  c.temper_b = vgpr_const(0x9d2c5680u);
+  c.temper_c = vgpr_const(0xefc60000u);
+  return c;
+}
+
 // tw(x[n], x[n+1]) of the twist  x[n + 624] = x[n + 397] ^ tw(x[n], x[n+1])  (oracle mt_twist):
 // y = top bit of x[n] with the low 31 of x[n+1]; (y >> 1) ^ (y odd ? 0x9908b0df : 0).  The callers keep
 // the halves h = x >> 1 of the words they walk over (each word is x[n+1] once and x[n] the step after):
 // y >> 1 is then h[n+1] with its bit 30 taken from h[n] -- one v_bfi_b32, whose mask 0x40000000 is the
 // inline constant 2.0.
-__device__ __forceinline__ uint32_t mt_twist_term(uint32_t hn, uint32_t hn1, uint32_t xn1) {
+__device__ __forceinline__ uint32_t mt_twist_term(uint32_t hn, uint32_t hn1, uint32_t xn1, const MtConsts &mc) {
   uint32_t ysh;  // (hn & 0x40000000) | (hn1 & ~0x40000000); left to itself hipcc takes three instructions
   asm("v_bfi_b32 %0, 2.0, %1, %2" : "=v"(ysh) : "v"(hn), "v"(hn1));
   const uint32_t odd = static_cast<uint32_t>(static_cast<int32_t>(xn1 << 31) >> 31);  // v_bfe_i32: all ones when odd
-  return __builtin_amdgcn_bitop3_b32(odd, 0x9908b0dfu, ysh, 0x6a);                   // (odd & magic) ^ (y >> 1)
+  return __builtin_amdgcn_bitop3_b32(odd, mc.magic, ysh, 0x6a);                       // (odd & magic) ^ (y >> 1)
 }
 
 // tempering (oracle mt_next); a ^ (b & c) is one v_bitop3_b32 (truth table 0x78)
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y, const MtConsts &mc) {
   y ^= y >> 11;
-  y = __builtin_amdgcn_bitop3_b32(y, y << 7, 0x9d2c5680u, 0x78);
-  y = __builtin_amdgcn_bitop3_b32(y, y << 15, 0xefc60000u, 0x78);
+  y = __builtin_amdgcn_bitop3_b32(y, y << 7, mc.temper_b, 0x78);
+  y = __builtin_amdgcn_bitop3_b32(y, y << 15, mc.temper_c, 0x78);
   y ^= y >> 18;
   return y;
 }
@@ -111,8 +124,8 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // Lemire map picks the table entry or rejects the output; an accepted one is a period
 // (src/simulations.cpp:250).
 template <bool kExactDiv>
-__device__ __forceinline__ bool offer(const RefArgs &k, const float *lds_table, uint32_t g, float &total, uint32_t &need) {
-  const uint32_t y = mt_temper(g);
+__device__ __forceinline__ bool offer(const RefArgs &k, const float *lds_table, const MtConsts &mc, uint32_t g, float &total, uint32_t &need) {
+  const uint32_t y = mt_temper(g, mc);
   const uint64_t prod = static_cast<uint64_t>(y) * k.table_len;
   const bool take = static_cast<uint32_t>(prod) >= k.reject_below && need != 0u;
   const float next = compound<kExactDiv>(total, lds_table[static_cast<uint32_t>(prod >> 32)]);
@@ -125,6 +138,7 @@ __device__ __forceinline__ bool offer(const RefArgs &k, const float *lds_table, 
 struct MtWindow {
   uint32_t seed, x397;  // x[0], x[397]: where the chains of the second stretch start
   uint32_t k;           // mt_multiplier()
+  MtConsts mc;          // mt_consts()
   uint32_t ah, a1, a1h; // x[j] >> 1, x[j + 1], x[j + 1] >> 1
   uint32_t b;           // j < 227: x[j + 397];  j >= 227: x[j + 170]
   uint32_t ch, c1, c1h; // j >= 227: x[j - 227] >> 1, x[j - 226], x[j - 226] >> 1
@@ -139,7 +153,7 @@ __device__ __forceinline__ void window_enter_a(MtWindow &w) {
 // `far` = j + 398, the index of the far chain's next word, is the caller's own scalar counter: formed
 // as j + 398 it is a second v_add per step (398 is no inline constant), as far + t it is part of a v_add3.
 __device__ __forceinline__ uint32_t window_next_a(MtWindow &w, uint32_t j, uint32_t far) {  // outputs 0 .. 226
-  const uint32_t g = w.b ^ mt_twist_term(w.ah, w.a1h, w.a1);
+  const uint32_t g = w.b ^ mt_twist_term(w.ah, w.a1h, w.a1, w.mc);
   w.ah = w.a1h;
   w.a1 = mt_seed_step(w.a1, j + 2u, w.k);
   w.a1h = w.a1 >> 1;
@@ -155,7 +169,7 @@ __device__ __forceinline__ void window_enter_b(MtWindow &w) {
 // `near` = j - 225 and `far` = j + 171: the next words of the two replayed chains (own counters, as above)
 __device__ __forceinline__ uint32_t window_next_b(MtWindow &w, uint32_t j, uint32_t near, uint32_t far) {  // outputs 227 .. 453
   // x[j + 397] = x[624 + (j - 227)] = x[j + 170] ^ tw(x[j - 227], x[j - 226]): output j - 227 again
-  const uint32_t g = xor3(w.b, mt_twist_term(w.ch, w.c1h, w.c1), mt_twist_term(w.ah, w.a1h, w.a1));
+  const uint32_t g = xor3(w.b, mt_twist_term(w.ch, w.c1h, w.c1, w.mc), mt_twist_term(w.ah, w.a1h, w.a1, w.mc));
   w.ah = w.a1h;
   w.a1 = mt_seed_step(w.a1, j + 2u, w.k);
   w.a1h = w.a1 >> 1;
@@ -171,44 +185,145 @@ __device__ __forceinline__ uint32_t window_next_b(MtWindow &w, uint32_t j, uint3
 // scalar mask) and the path is left to the generic kernel -- 1e-4 of the paths for the 1127-entry table
 // at 360 periods.  That keeps the loop free of per-lane state: no accept/select, no draw counter.
 //
-// kTraj (mc_simulations_keepdata, src/simulations.cpp:139-202: the same generator per path, every value
-// kept): lanes own paths, so one period's values are a column of the path-major output.  A wave parks
-// 32 periods x 64 paths in its own LDS tile ([64][33] words: the column writes and the row reads are both
-// conflict-free) and writes the tile out a row at a time -- 32 lanes one row's 128 contiguous bytes, two
-// rows per store instruction -- instead of 64 four-byte stores into 64 different lines per period.
-constexpr uint32_t kTrajTileCols = 32, kTrajTileStride = kTrajTileCols + 1;
-constexpr uint32_t kTrajTileWords = 64 * kTrajTileStride;  // per wave
+// kTraj (mc_simulations_keepdata, src/simulations.cpp:139-202: the same generator per path, every value kept).
+// Lanes own paths, so one period's values of a wave are a COLUMN of the path-major output, and rows are
+// 4 (P + 1) bytes apart: they begin at arbitrary offsets inside a 128-byte line.  Round 3 wrote 32-period
+// pieces of 64 ADJACENT rows wherever they fell: every line reached HBM as two partial writes 32 periods apart
+// (measured, profiles/r04/bench_ref_traj_before.jsonl: 1.65 TB/s at 4e6 x 361 values, WRITE_SIZE 1.32 x the
+// bytes stored).  Round 4 gives a wave the comb of keepdata_comb_kernel (smmc_kernels.hip):
+//   * lane l of wave w of a 2048-row super-chunk runs the K CONSECUTIVE rows 2048 s + 32 l + K w ...
+//     one after the other -- a stream of K (P + 1) contiguous floats.  32 rows are 32 (P + 1) floats, a whole
+//     number of lines, so all 64 streams of a wave start at the SAME offset phi inside a line: where a line ends
+//     is wave-uniform (a scalar column cursor, a scalar branch), no per-lane delay or predicate;
+//   * a stream's values go to a column-major LDS tile ([32 columns][64 lanes + 1]: conflict-free both ways) and
+//     every 32 columns the tile leaves as WHOLE aligned lines, 16 bytes per lane, 8 streams per store;
+//   * only the first and the last line of a stream are partial (one junction per K rows instead of two
+//     per row); a new generator per row costs nothing extra here -- every path starts one anyway (the Philox
+//     kernel has to recompute the head of the following row to close its last line);
+//   * 32 / K waves share a super-chunk: 8 / K workgroups of four waves.
+constexpr uint32_t kTrajSuper = 2048;              // rows per super-chunk: 64 lanes x 32
+// K, the consecutive rows per stream (RefArgs::traj_rows: 8, 4, 2 or 1), is the host's choice: 32 / K waves share a
+// super-chunk, i.e. 8 / K workgroups of four waves -- fewer rows per stream are more, shorter work units (a launch
+// of 4e6 rows is 1953 units at K = 8: not quite two rounds of the 1024 resident workgroups) against one more
+// junction line per K rows.
+constexpr uint32_t kTrajColStride = 65;            // words between two columns of a tile
+// A line is checked for completion once per TRIP of the period loops (four outputs), not per value -- the store
+// phase is ~150 instructions, and inlined behind every value of every stretch of the tree kernel it made 365 KB
+// of code and spilled -- so a tile holds up to 3 columns of the next line as well.
+constexpr uint32_t kTrajTrip = 4;
+constexpr uint32_t kTrajTileCols = 32 + kTrajTrip - 1;
+constexpr uint32_t kTrajTileWords = kTrajTileCols * kTrajColStride;  // per wave
 
-// Writes columns [0, count) of the wave's tile: value `first_k + c` of the rows row0 .. row0 + 63.
-__device__ __forceinline__ void traj_tile_flush(const RefArgs &k, const float *tile, uint32_t row0, uint32_t first_k, uint32_t count) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  const uint32_t lane = threadIdx.x & 63u, col = lane & 31u, half = lane >> 5;
-#pragma unroll 4
-  for (uint32_t rr = 0; rr < 32u; ++rr) {
-    const uint32_t r = 2u * rr + half;
-    const uint32_t row = row0 + r;
-    if (col < count && row < k.n_paths)
-      k.d_traj[static_cast<size_t>(row) * (k.n_periods + 1u) + first_k + col] = tile[r * kTrajTileStride + col];
+struct TrajWriter {
+  // wave-uniform
+  uint32_t col = 0;      // column of the next value: its float offset inside its 128-byte line
+  uint32_t win = 0;      // lines of the stream already stored
+  uint32_t phi = 0;      // column of the stream's first value
+  uint32_t stream0 = 0;  // first row of stream 0 (lane 0)
+  uint32_t n_rows = 0, row_len = 0, stream_len = 0, K = 0;
+  bool whole = false;    // every stream of this wave lies inside the launch
+  char *line0 = nullptr; // window 0 of stream 0
+  // per lane
+  float *mine = nullptr, *wp = nullptr;  // this lane's word of column 0 / of the next column
+  const float *take = nullptr;           // store phase: columns 4 quad .. + 3 of stream sub (+ 8 per iteration)
+  uint32_t lane_off = 0, sub = 0, quad = 0;
+
+  __device__ __forceinline__ void init(float *tile, uint32_t n_rows_, uint32_t n_periods, uint32_t rows_per_stream) {
+    const uint32_t lane = threadIdx.x & 63u;
+    sub = lane >> 3;
+    quad = lane & 7u;
+    mine = tile + lane;
+    take = tile + (4u * quad) * kTrajColStride + sub;
+    n_rows = n_rows_;
+    row_len = n_periods + 1u;
+    K = rows_per_stream;
+    stream_len = K * row_len;
+    lane_off = sub * (128u * row_len) + 16u * quad;  // 32 rows of 4 row_len bytes between two streams
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-}
+  // the wave's 64 streams begin at rows first_row + 32 lane
+  __device__ __forceinline__ void begin(float *d_traj, uint32_t first_row) {
+    stream0 = first_row;
+    const uint64_t first_f = (reinterpret_cast<uintptr_t>(d_traj) >> 2) + static_cast<uint64_t>(first_row) * row_len;
+    phi = static_cast<uint32_t>(first_f) & 31u;
+    line0 = reinterpret_cast<char *>(d_traj) + (static_cast<int64_t>(static_cast<uint64_t>(first_row) * row_len) - phi) * 4;
+    whole = static_cast<uint64_t>(first_row) + 32u * 63u + K <= n_rows;
+    col = phi;
+    win = 0;
+    wp = mine + col * kTrajColStride;
+  }
+  __device__ __forceinline__ void flush() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    char *line_t = line0 + win * 128u;
+    const uint64_t it_step = 1024ull * row_len;  // 8 streams further
+    const uint32_t o_first = 32u * win - phi;    // stream offset of column 0 (window 0: wraps below zero)
+    if (whole && win != 0u && o_first + 32u <= stream_len) {  // uniform: a whole line of every stream
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const float *src = take + 8 * it;
+        const float4 v = make_float4(src[0], src[kTrajColStride], src[2 * kTrajColStride], src[3 * kTrajColStride]);
+        *reinterpret_cast<float4 *>(line_t + it * it_step + lane_off) = v;
+      }
+    } else {
+      // a stream's first line (columns from phi on: the columns before belong to the stream of the rows before),
+      // its last line (up to its last value), streams that reach past the launch's last row
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const uint32_t r = sub + 8u * it;
+        const uint64_t first_row = static_cast<uint64_t>(stream0) + 32u * r;
+        const uint32_t rows_here = first_row >= n_rows ? 0u : (n_rows - first_row < K ? static_cast<uint32_t>(n_rows - first_row) : K);
+        const uint32_t valid = rows_here * row_len;
+        const float *src = take + 8 * it;
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+          const uint32_t o = o_first + 4u * quad + e;  // unsigned: columns before the stream wrap to huge values
+          if (o < valid) *reinterpret_cast<float *>(line_t + it * it_step + lane_off + 4u * e) = src[e * kTrajColStride];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    win += 1u;
+  }
+  // one value of the stream; at most kTrajTrip of them between two calls of line_check()
+  __device__ __forceinline__ void put(float v) {
+    *wp = v;
+    wp += kTrajColStride;
+    col += 1u;
+  }
+  // after a trip: a complete line goes out, the columns beyond it (at most kTrajTrip - 1) open the next one
+  __device__ __forceinline__ void line_check() {
+    if (col >= 32u) {  // uniform
+      flush();
+#pragma unroll
+      for (uint32_t c = 0; c + 1u < kTrajTrip; ++c) mine[c * kTrajColStride] = mine[(32u + c) * kTrajColStride];
+      col -= 32u;
+      wp = mine + col * kTrajColStride;
+    }
+  }
+  __device__ __forceinline__ void end() {
+    line_check();
+    if (col != 0u) flush();
+  }
+};
 
 template <int kDiv, bool kTraj>
 __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
   extern __shared__ __align__(16) float lds_table[];
   for (uint32_t i = threadIdx.x; i < k.table_len; i += kBlock) lds_table[i] = k.table_a[i];
   __syncthreads();
-  float *const tile = lds_table + ((k.table_len + 3u) & ~3u) + (threadIdx.x >> 6) * kTrajTileWords;  // kTraj only
   constexpr bool kExactDiv = kDiv == kDivExact;
   const uint32_t kmul = mt_multiplier();
+  const MtConsts mconst = mt_consts();
   const uint32_t P = k.n_periods;  // <= ref_windowed_max_outputs()
-  const uint32_t n_chunks = (k.n_paths + kBlock - 1u) / kBlock;  // n_paths <= 2^31
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const uint32_t i = chunk * kBlock + threadIdx.x;
+  TrajWriter tw;
+  if constexpr (kTraj) tw.init(lds_table + ((k.table_len + 3u) & ~3u) + (threadIdx.x >> 6) * kTrajTileWords, k.n_paths, P, k.traj_rows);
+
+  // one path: generator of seed0 + i, P periods, the final value (or the redo list)
+  auto run_path = [&](const uint32_t i) {
     MtWindow w;
     w.k = kmul;
+    w.mc = mconst;
     w.seed = k.seed0 + i;
     w.x397 = w.seed;
     w.x397 = mt_run_up(w.seed, w.k);
@@ -219,20 +334,22 @@ __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
     // writes the wave's 64 results to an SGPR pair, the OR is scalar: one VALU instruction per period)
     uint64_t redo_mask = 0;
     auto period = [&](uint32_t g, uint32_t j) {
-      const uint32_t y = mt_temper(g);
+      const uint32_t y = mt_temper(g, mconst);
       const uint64_t prod = static_cast<uint64_t>(y) * k.table_len;
       redo_mask |= __ballot(static_cast<uint32_t>(prod) < k.reject_below);
       total = compound<kExactDiv>(total, lds_table[static_cast<uint32_t>(prod >> 32)]);
       if constexpr (kDiv == kDivChecked) {  // the window of divide_kind() (smmc_capi.cpp): at least every 8 periods
         if ((j & 7u) == 7u) redo_mask |= __ballot(!(total > k.chk_lo && total < k.chk_hi));
       }
-      if constexpr (kTraj) {  // value j + 1 of the row goes to column j mod 32 of the tile
-        tile[(threadIdx.x & 63u) * kTrajTileStride + (j & 31u)] = total;
-        if ((j & 31u) == 31u) traj_tile_flush(k, tile, chunk * kBlock + (threadIdx.x & ~63u), j - 30u, 32u);
-      }
+      if constexpr (kTraj) tw.put(total);  // value j + 1 of the row
     };
+    auto trip_done = [&]() {
+      if constexpr (kTraj) tw.line_check();
+    };
+    static_assert(kTrajTrip == 4, "the period loops below make trips of four outputs");
     if constexpr (kTraj) {
-      if (i < k.n_paths) k.d_traj[static_cast<size_t>(i) * (P + 1u)] = total;  // values[0]: the initial capital
+      tw.put(total);  // values[0]: the initial capital
+      tw.line_check();
     }
     // four outputs per trip, written out (a loop holding a ballot is not unrolled with a remainder)
     uint32_t j = 0;
@@ -242,8 +359,12 @@ __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
       asm("" : "+s"(far));  // a scalar of its own (see window_next_a)
 #pragma unroll
       for (uint32_t t = 0; t < 4u; ++t) period(window_next_a(w, j + t, far + t), j + t);
+      trip_done();
     }
-    for (; j < first; ++j) period(window_next_a(w, j, j + kMtM + 1u), j);
+    for (; j < first; ++j) {
+      period(window_next_a(w, j, j + kMtM + 1u), j);
+      trip_done();
+    }
     if (P > kMtLag) {
       window_enter_b(w);
       for (; j + 4u <= P; j += 4u) {
@@ -252,11 +373,12 @@ __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
         asm("" : "+s"(far));
 #pragma unroll
         for (uint32_t t = 0; t < 4u; ++t) period(window_next_b(w, j + t, near + t, far + t), j + t);
+        trip_done();
       }
-      for (; j < P; ++j) period(window_next_b(w, j, j - kMtLag + 2u, j + kMtM - kMtLag + 1u), j);
-    }
-    if constexpr (kTraj) {
-      if (P & 31u) traj_tile_flush(k, tile, chunk * kBlock + (threadIdx.x & ~63u), (P & ~31u) + 1u, P & 31u);
+      for (; j < P; ++j) {
+        period(window_next_b(w, j, j - kMtLag + 2u, j + kMtM - kMtLag + 1u), j);
+        trip_done();
+      }
     }
     if (i < k.n_paths) {
       if ((redo_mask >> (threadIdx.x & 63u)) & 1u) {
@@ -265,6 +387,21 @@ __global__ __launch_bounds__(kBlock) void ref_windowed_kernel(const RefArgs k) {
         k.d_final[i] = total;
       }
     }
+  };
+
+  if constexpr (kTraj) {
+    const uint32_t K = k.traj_rows, per_super = 8u / K;  // workgroups per super-chunk
+    const uint32_t n_units = ((k.n_paths + kTrajSuper - 1u) / kTrajSuper) * per_super;  // n_paths <= 2^31
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+      const uint32_t first_row = (unit / per_super) * kTrajSuper + K * (kWaves * (unit % per_super) + wave);  // stream 0; lane l: + 32 l
+      tw.begin(k.d_traj, first_row);
+      for (uint32_t kk = 0; kk < K; ++kk) run_path(first_row + 32u * lane + kk);
+      tw.end();
+    }
+  } else {
+    const uint32_t n_chunks = (k.n_paths + kBlock - 1u) / kBlock;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) run_path(chunk * kBlock + threadIdx.x);
   }
 }
 
@@ -378,6 +515,7 @@ static_assert(Tree<kTreeMaxShort>::t.w[Tree<kTreeMaxShort>::t.n - 1] == int(kMtN
 
 struct TreeSeeds {
   uint32_t seed, x1, x397, k;  // x[0], x[1], x[397], mt_multiplier()
+  MtConsts mc;                 // mt_consts()
 };
 struct TreeState {
   uint32_t s[kTreeCap];  // per stream: the chain's word x[n + W] (seed form) or word(n + W - 624) >> 1 (made)
@@ -407,7 +545,7 @@ __device__ __forceinline__ void tree_eval(TreeState &st, TreeWords &v, uint32_t 
         static_assert(Tr::live(kT, kNear) && Tr::live(kT, kFar) && kNear < kI && kFar < kI, "operands come first");
         const uint32_t a1 = tree_single<kMax, kT, kNear>(v);
         const uint32_t a1h = a1 >> 1;
-        const uint32_t term = mt_twist_term(st.s[kI], a1h, a1);
+        const uint32_t term = mt_twist_term(st.s[kI], a1h, a1, sd.mc);
         st.s[kI] = a1h;
         if constexpr (Tr::is_pair(kT, kFar)) {
           v.p[kI] = xor3(v.p[kFar], v.q[kFar], term);
@@ -438,8 +576,8 @@ __device__ __forceinline__ void tree_begin(TreeState &st, const TreeSeeds &sd) {
 }
 
 // outputs [stretch kS, min(P, stretch kS + 1)), then the stretches after it
-template <int kMax, int kS, typename Period>
-__device__ __forceinline__ void tree_run_stretch(TreeState &st, const TreeSeeds &sd, uint32_t P, Period &period) {
+template <int kMax, int kS, typename Period, typename TripDone>
+__device__ __forceinline__ void tree_run_stretch(TreeState &st, const TreeSeeds &sd, uint32_t P, Period &period, TripDone &trip_done) {
   using Tr = Tree<kMax>;
   constexpr int kT = Tr::t.stretch[kS];
   if (P <= static_cast<uint32_t>(kT)) return;
@@ -455,9 +593,13 @@ __device__ __forceinline__ void tree_run_stretch(TreeState &st, const TreeSeeds 
   for (; j + 4u <= end; j += 4u) {  // four outputs per trip, written out (a loop holding a ballot is not unrolled with a remainder)
 #pragma unroll
     for (uint32_t t = 0; t < 4u; ++t) period(output(j + t), j + t);
+    trip_done();
   }
-  for (; j < end; ++j) period(output(j), j);
-  if constexpr (kS + 1 < Tr::t.n_stretch) tree_run_stretch<kMax, kS + 1>(st, sd, P, period);
+  for (; j < end; ++j) {
+    period(output(j), j);
+    trip_done();
+  }
+  if constexpr (kS + 1 < Tr::t.n_stretch) tree_run_stretch<kMax, kS + 1>(st, sd, P, period, trip_done);
 }
 
 // As ref_windowed_kernel (rejections and checked-divide leavers flagged for the redo launch, kTraj through the
@@ -467,14 +609,15 @@ __global__ __launch_bounds__(kBlock) void ref_tree_kernel(const RefArgs k) {
   extern __shared__ __align__(16) float lds_table[];
   for (uint32_t i = threadIdx.x; i < k.table_len; i += kBlock) lds_table[i] = k.table_a[i];
   __syncthreads();
-  float *const tile = lds_table + ((k.table_len + 3u) & ~3u) + (threadIdx.x >> 6) * kTrajTileWords;  // kTraj only
   constexpr bool kExactDiv = kDiv == kDivExact;
   TreeSeeds sd;
   sd.k = mt_multiplier();
+  sd.mc = mt_consts();
   const uint32_t P = k.n_periods;  // <= kMax
-  const uint32_t n_chunks = (k.n_paths + kBlock - 1u) / kBlock;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const uint32_t i = chunk * kBlock + threadIdx.x;
+  TrajWriter tw;
+  if constexpr (kTraj) tw.init(lds_table + ((k.table_len + 3u) & ~3u) + (threadIdx.x >> 6) * kTrajTileWords, k.n_paths, P, k.traj_rows);
+
+  auto run_path = [&](const uint32_t i) {
     sd.seed = k.seed0 + i;
     sd.x1 = mt_seed_step(sd.seed, 1u, sd.k);
     sd.x397 = mt_run_up(sd.seed, sd.k);
@@ -482,25 +625,23 @@ __global__ __launch_bounds__(kBlock) void ref_tree_kernel(const RefArgs k) {
     float total = k.initial_capital;
     uint64_t redo_mask = 0;
     auto period = [&](uint32_t g, uint32_t j) {
-      const uint32_t y = mt_temper(g);
+      const uint32_t y = mt_temper(g, sd.mc);
       const uint64_t prod = static_cast<uint64_t>(y) * k.table_len;
       redo_mask |= __ballot(static_cast<uint32_t>(prod) < k.reject_below);
       total = compound<kExactDiv>(total, lds_table[static_cast<uint32_t>(prod >> 32)]);
       if constexpr (kDiv == kDivChecked) {
         if ((j & 7u) == 7u) redo_mask |= __ballot(!(total > k.chk_lo && total < k.chk_hi));
       }
-      if constexpr (kTraj) {
-        tile[(threadIdx.x & 63u) * kTrajTileStride + (j & 31u)] = total;
-        if ((j & 31u) == 31u) traj_tile_flush(k, tile, chunk * kBlock + (threadIdx.x & ~63u), j - 30u, 32u);
-      }
+      if constexpr (kTraj) tw.put(total);
+    };
+    auto trip_done = [&]() {
+      if constexpr (kTraj) tw.line_check();
     };
     if constexpr (kTraj) {
-      if (i < k.n_paths) k.d_traj[static_cast<size_t>(i) * (P + 1u)] = total;
+      tw.put(total);
+      tw.line_check();
     }
-    tree_run_stretch<kMax, 0>(st, sd, P, period);
-    if constexpr (kTraj) {
-      if (P & 31u) traj_tile_flush(k, tile, chunk * kBlock + (threadIdx.x & ~63u), (P & ~31u) + 1u, P & 31u);
-    }
+    tree_run_stretch<kMax, 0>(st, sd, P, period, trip_done);
     if (i < k.n_paths) {
       if ((redo_mask >> (threadIdx.x & 63u)) & 1u) {
         k.redo_list[atomicAdd(k.redo_count, 1u)] = i;
@@ -508,6 +649,21 @@ __global__ __launch_bounds__(kBlock) void ref_tree_kernel(const RefArgs k) {
         k.d_final[i] = total;
       }
     }
+  };
+
+  if constexpr (kTraj) {  // the comb of ref_windowed_kernel
+    const uint32_t K = k.traj_rows, per_super = 8u / K;
+    const uint32_t n_units = ((k.n_paths + kTrajSuper - 1u) / kTrajSuper) * per_super;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+      const uint32_t first_row = (unit / per_super) * kTrajSuper + K * (kWaves * (unit % per_super) + wave);
+      tw.begin(k.d_traj, first_row);
+      for (uint32_t kk = 0; kk < K; ++kk) run_path(first_row + 32u * lane + kk);
+      tw.end();
+    }
+  } else {
+    const uint32_t n_chunks = (k.n_paths + kBlock - 1u) / kBlock;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) run_path(chunk * kBlock + threadIdx.x);
   }
 }
 
@@ -526,12 +682,14 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
   const uint32_t count = k.redo_list ? *k.redo_count : k.n_paths;
   const uint32_t P = k.n_periods;
   const uint32_t kmul = mt_multiplier();
+  const MtConsts mconst = mt_consts();
   for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kBlock; base < count; base += L) {
     const uint64_t item = base + threadIdx.x;
     const bool active = item < count;
     const uint32_t i = !active ? 0u : (k.redo_list ? k.redo_list[item] : static_cast<uint32_t>(item));
     MtWindow w;
     w.k = kmul;
+    w.mc = mconst;
     w.seed = k.seed0 + i;
     w.x397 = w.seed;
     float total = k.initial_capital;
@@ -542,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
       if (active) row[0] = total;
     }
     auto use = [&](uint32_t g) {
-      const bool took = offer<kExactDiv>(k, lds_table, g, total, need);
+      const bool took = offer<kExactDiv>(k, lds_table, w.mc, g, total, need);
       if constexpr (kTraj) {
         if (took) row[P - need] = total;
       }
@@ -572,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
         uint32_t m[4];
         for (uint32_t t = 0; t < n_here; ++t) m[t] = W[static_cast<size_t>(j + t - kMtLag) * L];
         for (uint32_t t = 0; t < n_here; ++t) {
-          const uint32_t g = m[t] ^ mt_twist_term(w.ah, w.a1h, w.a1);
+          const uint32_t g = m[t] ^ mt_twist_term(w.ah, w.a1h, w.a1, w.mc);
           w.ah = w.a1h;
           // x[j + t + 2]: a seed word, or -- the last two outputs of this stretch -- generated word 0 / 1
           w.a1 = j + t + 2u < kMtN ? mt_seed_step(w.a1, j + t + 2u, w.k) : W[static_cast<size_t>(j + t + 2u - kMtN) * L];
@@ -598,7 +756,7 @@ __global__ __launch_bounds__(kBlock) void ref_generic_kernel(const RefArgs k) {
 #pragma unroll
       for (uint32_t t = 0; t < 8; ++t) {
         const uint32_t n1h = n1[t] >> 1;
-        const uint32_t g = m[t] ^ mt_twist_term(xnh, n1h, n1[t]);
+        const uint32_t g = m[t] ^ mt_twist_term(xnh, n1h, n1[t], w.mc);
         W[static_cast<size_t>(s + t) * L] = g;  // x[j + t + 624] takes the place of x[j + t]
         use(g);
         xnh = n1h;
@@ -688,6 +846,11 @@ hipError_t launch_ref_tree(const RefArgs &a, int div, bool traj, uint32_t grid, 
 hipError_t launch_ref_windowed(const RefArgs &a, int div, uint32_t grid, hipStream_t stream) {
   const bool traj = a.d_traj != nullptr;
   const size_t lds = ref_windowed_lds_bytes(a.table_len, traj);
+  if (traj) {  // a workgroup takes 8 / K-th of a super-chunk of 2048 rows, not a chunk of 256
+    if (a.traj_rows != 8u && a.traj_rows != 4u && a.traj_rows != 2u && a.traj_rows != 1u) return hipErrorInvalidValue;
+    const uint32_t n_units = ((a.n_paths + kTrajSuper - 1u) / kTrajSuper) * (8u / a.traj_rows);
+    grid = grid < n_units ? grid : n_units;
+  }
   // SMMC_REF_KERNEL=tree (test / measurement knob): the tree form also for the lengths the hand-written one takes
   const char *env = std::getenv("SMMC_REF_KERNEL");
   const bool tree_always = env && !std::strcmp(env, "tree");

@@ -150,6 +150,14 @@ class Engine:
         _lib.check(self._L.smmc_engine_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernel_clock_ghz(self):
+        """The shader clock the chip held, averaged over the workgroups of the path-kernel launches timed since the
+        last call (0.0 if none was sampled); synchronises."""
+        ghz = C.c_double()
+        self._enter()
+        _lib.check(self._L.smmc_engine_kernel_clock(self._h, C.byref(ghz)))
+        return ghz.value
+
     def selftest(self, bits_lo, bits_hi):
         """Mismatches of the device's divide-by-100 shortcut vs the IEEE divide on [lo, hi)."""
         a = C.c_uint64()

@@ -66,11 +66,6 @@ hipError_t launch_paths(const KernelArgs &a, int, uint32_t grid, size_t, hipStre
     none.min = std::numeric_limits<float>::infinity();
     none.max = -none.min;
     for (uint32_t g = 0; g < grid; ++g) a.partials[g] = g == 0 ? t : none;
-    if (a.d_stats_out) {  // the last workgroup's fold
-      smmc_stats *o = a.d_stats_out;
-      o->count = t.count; o->below = t.below; o->underflow = t.underflow; o->overflow = t.overflow;
-      o->sum = t.sum; o->sumsq = t.sumsq; o->min = t.min; o->max = t.max; o->n_bins = a.n_bins; o->reserved = 0;
-    }
   }
   return hipSuccess;
 }
@@ -92,8 +87,7 @@ hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, sm
   return hipSuccess;
 }
 
-uint32_t paths_resident_per_cu(const KernelArgs &, int, size_t) { return 4; }
-size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins, int) { return (static_cast<size_t>(table_len) + n_bins) * 4u + 14336u; }
+size_t paths_lds_bytes(uint32_t table_len, uint32_t n_bins, int) { return (static_cast<size_t>(table_len) + n_bins) * 4u ; }
 hipError_t static_lds_bytes(size_t *bytes) { *bytes = 0; return hipSuccess; }
 size_t bm_tables_bytes(int stream) { return stream == 2 ? (1056 * 4 + 256 * 2) * 4 : (512 * 4 + 2048 * 2) * 4; }
 

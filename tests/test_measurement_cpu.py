@@ -126,7 +126,7 @@ def test_pmc_traffic_belongs_to_the_kernels_as_they_compile_now(asm, ref_asm, tm
             assert src == "smmc_ref_kernels.hip"
             path = ref_asm
         assert rec["isa_fingerprint"] == I.fingerprint(path, variant, kernel), (
-            f"{key}: the kernel changed since the PMC pass ({rec['source']}): run tools/profile_r03.sh again")
+            f"{key}: the kernel changed since the PMC pass ({rec['source']}): run tools/profile_r04.sh again")
         assert rec["source_sha256"] == I.source_digest(mode), f"{key}: kernel sources or flags changed since the PMC pass"
     b, src = bench.pmc_traffic("gaussian", 100_000_000, 360, "all")
     assert b and src and src.startswith("profiles/")
@@ -142,3 +142,41 @@ def test_pmc_traffic_belongs_to_the_kernels_as_they_compile_now(asm, ref_asm, tm
         assert b is None and why.startswith("stale")
     finally:
         bench.PMC_TRAFFIC_FILE = old
+
+
+def test_weighted_valu_model_prices_the_loops_as_they_compile_now(asm):
+    """bench.py's valu.weighted_frac = (the period loop priced with this round's measured per-opcode issue costs) /
+    (measured time at the held clock).  The priced loop is stored beside the PMC traffic of the same build; here it is
+    re-derived from the kernels as they compile now and from profiles/r04/ubench_ops.jsonl: no opcode of the two hot
+    loops is priced by assumption, the stored figure is the current one, and the table says what DESIGN.md section 5
+    says it says (half-rate multiplies, conversions, SDWA; an SGPR source alone halves the rate; full-rate v_bitop3)."""
+    import bench
+    import isa_loop_count as I
+    import valu_model as V
+    ops = V.load_table()
+    stored = json.load(open(bench.PMC_TRAFFIC_FILE))
+    for mode, key in (("gaussian", "gaussian|100000000|360|all"), ("table", "table|100000000|360|all")):
+        variant, periods = I.VARIANTS[mode]
+        rows, assumed = V.price(V.loop_lines(asm, variant), ops)
+        assert not assumed, assumed
+        m = V.model(rows)
+        assert m["valu_insts"] == pytest.approx(bench.VALU_INSTS_PER_STEP[mode] * periods)
+        assert m["model_clk"] == m["pipe_clk"] > m["sgpr_port_clk"]  # the scalar-operand port is not what binds these loops
+        rec = stored[key]["valu"]
+        assert rec["model_clk_per_block"] == pytest.approx(m["model_clk"], rel=1e-9) and rec["periods_per_block"] == periods
+        assert os.path.exists(os.path.join(ROOT, rec["weights_source"].split(" ")[0]))
+    full, half = 2.0, 4.0
+    def clk(probe, operands):
+        return ops[(probe, operands)]
+    assert all(abs(clk(*k) - full) < 0.35 for k in (("v_xor_b32", "vgpr"), ("v_mul_f32", "vgpr"), ("v_add_u32", "vgpr"),
+                                                    ("v_fma_f32", "three distinct vgprs"), ("v_lshrrev_b32", "inline"),
+                                                    ("v_bitop3_b32", "explicit registers, three banks")))
+    assert all(abs(clk(*k) - half) < 0.35 for k in (("v_mad_u64_u32", "vgpr, vcc carry"), ("v_mul_lo_u32", "vgpr"),
+                                                    ("v_cvt_f32_i32", "vgpr"), ("v_and_b32_sdwa", "vgpr"), ("v_and_or_b32", "vgpr"),
+                                                    ("v_lshlrev_b32", "inline"), ("v_xor_b32", "sgpr"), ("v_mul_f32", "sgpr"),
+                                                    ("v_bitop3_b32", "sgpr")))
+    # the port: one SGPR reader among VGPR-only instructions costs nothing extra; a simple integer operation next to a
+    # multiply costs a multiply's time; a binary32 FMA next to a multiply does not
+    assert clk("mix: v_xor sgpr + 3 vgpr-only", "per GROUP of 4: count x 4") < 4 * full + 1.0
+    assert clk("mix: v_mad_u64_u32 + v_xor vgpr", "per GROUP of 2: count x 2") > 2 * half - 0.5
+    assert clk("order: 32 v_mad_u64_u32 + 32 v_fma_f32", "runs of 1 (alternating)") < 3.3

@@ -319,3 +319,57 @@ def test_full_size_properties_of_the_reference_stream(eng, oracle, table):
     for first in (0, (1 << 27) - 150, n2 - 300):
         want, _ = oracle.ref_mc_simulations(300, 2, 1000.0, table, seed0 + first)
         assert np.array_equal(_bits(g[first:first + 300]), _bits(want)), first
+
+
+@pytest.mark.parametrize("n,p,shift", [(3 * 2048 + 77, 360, 0), (2 * 2048 + 1, 361, 3), (5000, 63, 17), (4096, 1000, 1),
+                                       (2049, 32, 31), (10000, 5, 7), (2048, 31, 9), (6000, 0, 5)])
+def test_comb_trajectories_every_row_and_nothing_else(eng, oracle, table, n, p, shift):
+    """Round 4's trajectory writer (TrajWriter, csrc/smmc_ref_kernels.hip): a lane runs eight consecutive rows,
+    lanes are 32 rows apart, four waves share a 2048-row super-chunk, every 128-byte line leaves as a whole.
+    Several super-chunks with a ragged last one, row lengths that are and are not multiples of a line, base
+    pointers at every kind of offset inside a line: EVERY row equals many_updates of its own generator's draws,
+    and the floats before and after the array keep their sentinel."""
+    import ctypes as C
+    import torch
+    from stock_market_monte_carlo_amd import _lib
+    seed0, guard = 77_000 + n, 64
+    row = p + 1
+    buf = torch.full((guard + shift + n * row + guard,), float("nan"), dtype=torch.float32, device=eng.tdevice)
+    fin = torch.full((n + 2,), float("nan"), dtype=torch.float32, device=eng.tdevice)
+    traj = buf[guard + shift:guard + shift + n * row]
+    sim = _sim(n, p, seed0)
+    eng._enter()
+    _lib.check(eng._L.smmc_engine_simulate_keepdata(eng._h, C.byref(sim), C.c_void_p(traj.data_ptr()), C.c_void_p(fin[1:].data_ptr())))
+    eng.sync()
+    host = buf.cpu().numpy()
+    assert np.isnan(host[:guard + shift]).all() and np.isnan(host[guard + shift + n * row:]).all()
+    f = fin.cpu().numpy()
+    assert np.isnan(f[0]) and np.isnan(f[-1])
+    got = host[guard + shift:guard + shift + n * row].reshape(n, row)
+    want_final, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
+    assert np.array_equal(_bits(f[1:-1]), _bits(want_final)) and np.array_equal(_bits(got[:, -1]), _bits(want_final))
+    assert np.all(got[:, 0] == np.float32(1000.0))
+    step = 1 if n * row <= 1_500_000 else 7  # every row of the smaller shapes, every seventh (+ the edges) of the larger
+    rows = sorted(set(range(0, n, step)) | set(range(0, 80)) | set(range(2040, min(n, 2060))) | set(range(max(0, n - 70), n)))
+    for i in rows:
+        idx = oracle.mt19937_indices((seed0 + i) & 0xFFFFFFFF, table.size, p)
+        want = oracle.many_updates(1000.0, table[idx], p) if p else np.array([1000.0], dtype=np.float32)
+        assert np.array_equal(_bits(got[i]), _bits(want)), (n, p, shift, i)
+
+
+@pytest.mark.parametrize("rows", [1, 2, 4, 8])
+@pytest.mark.parametrize("p", [360, 1000])
+def test_comb_trajectories_do_not_depend_on_the_rows_per_stream(eng, oracle, table, monkeypatch, rows, p):
+    """SMMC_REF_TRAJ_ROWS (the consecutive rows a lane runs: 8 / K workgroups share a 2048-row super-chunk): the same
+    trajectories for every setting, rows across streams, waves, workgroups and the ragged last super-chunk against
+    the oracle (windowed kernel at 360 periods, tree kernel at 1000)."""
+    monkeypatch.setenv("SMMC_REF_TRAJ_ROWS", str(rows))
+    n, seed0 = 2 * 2048 + 333, 5_000_000
+    traj, final = eng.simulate_keepdata(_sim(n, p, seed0))
+    eng.sync()
+    got = traj.cpu().numpy()
+    want_final, _ = oracle.ref_mc_simulations(n, p, 1000.0, table, seed0)
+    assert np.array_equal(_bits(got[:, -1]), _bits(want_final)) and np.array_equal(_bits(final.cpu().numpy()), _bits(want_final))
+    for i in list(range(0, 70)) + list(range(2040, 2120)) + list(range(4090, n)) + list(range(500, 4000, 97)):
+        idx = oracle.mt19937_indices((seed0 + i) & 0xFFFFFFFF, table.size, p)
+        assert np.array_equal(_bits(got[i]), _bits(oracle.many_updates(1000.0, table[idx], p))), (rows, p, i)

@@ -24,9 +24,18 @@ def traj_cases():
     import torch
     from stock_market_monte_carlo_amd import _lib
     table = load_table()
-    cases = (("ref windowed traj", 4_000_000, 360, "ref"), ("philox table traj", 4_000_000, 360, 3),
-             ("ref tree traj", 1_500_000, 1000, "ref"), ("philox table traj", 1_500_000, 1000, 3))
-    for name, n, p, stream in cases:
+    cases = (("ref windowed traj", 4_000_000, 360, "ref", ""), ("ref windowed traj", 4_000_000, 360, "ref", "8"),
+             ("ref windowed traj", 4_000_000, 360, "ref", "4"), ("ref windowed traj", 4_000_000, 360, "ref", "2"),
+             ("ref windowed traj", 4_000_000, 360, "ref", "1"), ("philox table traj", 4_000_000, 360, 3, ""),
+             ("ref tree traj", 1_500_000, 1000, "ref", ""), ("ref tree traj", 1_500_000, 1000, "ref", "8"),
+             ("ref tree traj", 1_500_000, 1000, "ref", "4"), ("ref tree traj", 1_500_000, 1000, "ref", "2"),
+             ("ref tree traj", 1_500_000, 1000, "ref", "1"), ("philox table traj", 1_500_000, 1000, 3, ""),
+             ("ref windowed traj", 16_000_000, 360, "ref", ""))
+    for name, n, p, stream, rows in cases:
+        if rows:
+            os.environ["SMMC_REF_TRAJ_ROWS"] = rows  # read at every call; "" = the library's own choice
+        else:
+            os.environ.pop("SMMC_REF_TRAJ_ROWS", None)
         eng = S.Engine(0)
         eng.set_table(table)
         sim = S.Engine.make_sim(n, p, S.MODE_TABLE, 1000, stream=stream)
@@ -50,7 +59,7 @@ def traj_cases():
             rounds.append(ms / 10)
         ms = sorted(rounds)[2]
         b = 4.0 * n * (p + 1)
-        print(json.dumps({"case": name, "n_paths": n, "n_periods": p, "kernel_ms": ms, "bytes": b, "TBps": b / ms / 1e9,
+        print(json.dumps({"case": name, "rows_per_stream": rows or "auto", "n_paths": n, "n_periods": p, "kernel_ms": ms, "bytes": b, "TBps": b / ms / 1e9,
                           "frac_of_8TBps": b / ms / 1e9 / 8.0, "rounds_ms": rounds,
                           "divide": ("fast", "exact", "checked")[eng.divide_kind(sim, keepdata=True)],
                           "last_column_mean": float(traj[:, -1].double().mean()), "final_mean": float(final.double().mean())}), flush=True)

@@ -34,6 +34,19 @@ def build_identity(mode):
             "source_sha256": I.source_digest(mode)}
 
 
+def valu_model_of(mode):
+    """The kernel's period loop priced with the round's per-opcode issue costs (tools/valu_model.py): what bench.py's
+    valu.weighted_frac is computed from.  Belongs to the build like the traffic figure (same fingerprint)."""
+    import valu_model as V
+    name = {"gaussian": "gaussian", "table": "table", "ref": "ref"}.get(mode)
+    if name is None:
+        return None
+    m = V.kernel_model(name)
+    return {"model_clk_per_block": m["model_clk"], "pipe_clk": m["pipe_clk"], "sgpr_readers": m["sgpr_readers"],
+            "valu_insts_per_block": m["valu_insts"], "periods_per_block": m["periods_per_block"], "assumed_opcodes": m["assumed"],
+            "weights_source": m["weights_source"] + " (tools/ubench_ops.hip, %d waves per SIMD; tools/valu_model.py)" % m["waves_per_simd_of_the_weights"]}
+
+
 def mean_counter(directory, counter, kernel="paths_kernel"):
     vals = []
     for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
@@ -66,7 +79,7 @@ def main():
     except (OSError, ValueError):
         table = {}
     table[a.key] = {"bytes": (w + 2.0 * f) * 1024.0, "write_size_kib": w, "fetch_size_kib": f,
-                    "dispatches": [nw, nf], "source": a.source, **build_identity(mode),
+                    "dispatches": [nw, nf], "source": a.source, **build_identity(mode), "valu": valu_model_of(mode),
                     "correction": "WRITE_SIZE KiB x 1024 + 2 x FETCH_SIZE KiB x 1024 (gfx950 read counter tallies "
                                   "128-byte requests at 64 bytes)"}
     with open(a.out, "w") as fh:

@@ -72,7 +72,7 @@ __device__ __forceinline__ void table_block(Regs &r, unsigned k, float kf) {
 }
 
 template <int MIX>
-__global__ __launch_bounds__(256) void probe(unsigned *out, unsigned k, float kf, unsigned long long *clk) {
+__global__ __launch_bounds__(256) void probe(unsigned *out, unsigned k, float kf, unsigned long long *clk, int n_blocks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   Regs r;
   for (int i = 0; i < 4; ++i) {
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void probe(unsigned *out, unsigned k, float kf
     r.w[i] = r.a[i];
     r.f[i] = 1.0f + i * 0.25f;
   }
-  for (int i = 0; i < kBlocks; ++i) {
+  for (int i = 0; i < n_blocks; ++i) {
     if constexpr (MIX == 0) gaussian_block(r, k, kf);
     else table_block(r, k, kf);
   }
@@ -96,11 +96,11 @@ int run(const char *name, int insts, int waves_per_simd, unsigned *d_out, int cu
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int w = 0; w < 20; ++w) hipLaunchKernelGGL(probe<MIX>, dim3(grid), dim3(256), 0, 0, d_out, 3u, 1.5f, d_clk);
+  for (int w = 0; w < 20; ++w) hipLaunchKernelGGL(probe<MIX>, dim3(grid), dim3(256), 0, 0, d_out, 3u, 1.5f, d_clk, kBlocks);
   CK(hipDeviceSynchronize());
   const int reps = 5;
   CK(hipEventRecord(e0));
-  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(probe<MIX>, dim3(grid), dim3(256), 0, 0, d_out, 5u, 1.5f, d_clk);
+  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(probe<MIX>, dim3(grid), dim3(256), 0, 0, d_out, 5u, 1.5f, d_clk, kBlocks);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -120,6 +120,38 @@ int run(const char *name, int insts, int waves_per_simd, unsigned *d_out, int cu
   return 0;
 }
 
+// Sustained load: launches as long as paths_kernel's (1e8 x 360 Gaussian paths are 137 329 blocks per SIMD: 34 332 per
+// wave at four waves per SIMD, ~13 ms), back to back for a quarter of a second: which clock does the chip HOLD under
+// this instruction mix, and how long does a block take then?
+template <int MIX>
+int sustained(const char *name, int insts, int waves_per_simd, int n_blocks, int launches, unsigned *d_out, int cus, unsigned long long *d_clk) {
+  const int grid = cus * waves_per_simd;
+  std::vector<unsigned long long> h(2 * grid);
+  for (int l = 0; l < launches; ++l) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(probe<MIX>, dim3(grid), dim3(256), 0, 0, d_out, 5u, 1.5f, d_clk, n_blocks);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(h.data(), d_clk, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
+    double ticks = 0, real = 0;
+    for (int i = 0; i < grid; ++i) { ticks += (double)h[2 * i]; real += (double)h[2 * i + 1]; }
+    const double ghz = ticks / real * 0.1;
+    const double ns_per_block = ms * 1e6 / ((double)n_blocks * waves_per_simd);
+    if (l < 3 || l % 8 == 7 || l + 1 == launches)
+      printf("{\"probe\": \"%s sustained\", \"valu_insts_per_block\": %d, \"waves_per_simd\": %d, \"launch\": %d, \"ms\": %.3f, "
+             "\"clock_ghz\": %.3f, \"ns_per_block_per_simd\": %.3f, \"clk_per_block\": %.2f}\n", name, insts, waves_per_simd, l, ms, ghz,
+             ns_per_block, ns_per_block * ghz);
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+  }
+  return 0;
+}
+
 int main() {
   hipDeviceProp_t p;
   CK(hipGetDeviceProperties(&p, 0));
@@ -133,5 +165,7 @@ int main() {
     if (run<0>("mix_gaussian_block", 70, w, d_out, cus, d_clk)) return 1;
     if (run<1>("mix_table_block", 84, w, d_out, cus, d_clk)) return 1;
   }
+  if (sustained<0>("mix_gaussian_block", 70, 4, 34332, 24, d_out, cus, d_clk)) return 1;
+  if (sustained<1>("mix_table_block", 84, 8, 8583, 24, d_out, cus, d_clk)) return 1;
   return 0;
 }
