@@ -727,11 +727,12 @@ def main():
         # time at the clock the chip held while it ran -- sampled live by the launches' own workgroups
         model, model_src = (pmc_traffic(mode_name, n, periods, outputs, want="valu") if args.stream == "3" and kind == 0
                             else (None, None))
-        weighted_frac = None
+        weighted_frac = weighted_frac_measured = None
         if model and k_avg_s > 0 and held_clock_ghz > 0:
             simds = eng.geometry()[2] * 4
             blocks_per_simd = paths_per_launch * periods / model["periods_per_block"] / 64.0 / simds
-            weighted_frac = model["model_clk_per_block"] * blocks_per_simd / (k_avg_s * held_clock_ghz * 1e9)
+            weighted_frac = model["class_clk_per_block"] * blocks_per_simd / (k_avg_s * held_clock_ghz * 1e9)
+            weighted_frac_measured = model["model_clk_per_block"] * blocks_per_simd / (k_avg_s * held_clock_ghz * 1e9)
         if world == 1:
             par = "single GPU"
         elif to_host:
@@ -772,16 +773,20 @@ def main():
                      # (4 bytes written per path), against the ridge point peak ops / peak bytes
                      "arithmetic_intensity": (periods * insts / 4.0) if (insts and writes_final) else None,
                      "ridge_point": VALU_PEAK_LANEOPS / (HBM_PEAK_GBS * 1e9),
-                     "weighted_frac": weighted_frac,
-                     "weighted_model": ({"clk_per_block": model["model_clk_per_block"], "periods_per_block": model["periods_per_block"],
+                     "weighted_frac": weighted_frac, "weighted_frac_measured_costs": weighted_frac_measured,
+                     "weighted_model": ({"class_clk_per_block": model["class_clk_per_block"],
+                                         "half_rate_insts_per_block": model["half_rate_insts_per_block"],
+                                         "measured_cost_clk_per_block": model["model_clk_per_block"],
+                                         "periods_per_block": model["periods_per_block"],
                                          "valu_insts_per_block": model["valu_insts_per_block"], "source": model_src}
                                         if model else None),
                      "held_clock_ghz": held_clock_ghz or None,
                      "held_clock_source": ("live: s_memtime / s_memrealtime of every workgroup of the timed launches "
                                            "(smmc_engine_kernel_clock)") if held_clock_ghz else None,
                      "note": "frac is unweighted: every VALU instruction counted as one 2-clock issue slot at the 2.4 GHz peak; "
-                             "weighted_frac prices every opcode with its measured issue cost (isolated streams) and uses "
-                             "the clock the chip held; arithmetic_intensity in lane-ops per HBM byte"},
+                             "weighted_frac prices every opcode at its class cost (2 clocks full rate, 4 half rate: the "
+                             "classes measured by tools/ubench_ops.hip) and uses the clock the chip held; "
+                             "weighted_frac_measured_costs uses the probes' measured costs, which carry their own overhead; arithmetic_intensity in lane-ops per HBM byte"},
         }
         if to_host:
             out["host_pipeline"] = {"bytes_to_host_per_step": 4.0 * n, "GBps_rank0": 4.0 * n * args.steps / dt / 1e9,

@@ -164,6 +164,8 @@ def test_weighted_valu_model_prices_the_loops_as_they_compile_now(asm):
         assert m["model_clk"] == m["pipe_clk"] > m["sgpr_port_clk"]  # the scalar-operand port is not what binds these loops
         rec = stored[key]["valu"]
         assert rec["model_clk_per_block"] == pytest.approx(m["model_clk"], rel=1e-9) and rec["periods_per_block"] == periods
+        assert rec["class_clk_per_block"] == m["class_clk"] == 2.0 * m["valu_insts"] + 2.0 * m["half_rate_insts"]
+        assert m["class_clk"] < m["model_clk"] < 1.12 * m["class_clk"]  # the probes' overhead: a few per cent
         assert os.path.exists(os.path.join(ROOT, rec["weights_source"].split(" ")[0]))
     full, half = 2.0, 4.0
     def clk(probe, operands):

@@ -42,7 +42,8 @@ def valu_model_of(mode):
     if name is None:
         return None
     m = V.kernel_model(name)
-    return {"model_clk_per_block": m["model_clk"], "pipe_clk": m["pipe_clk"], "sgpr_readers": m["sgpr_readers"],
+    return {"class_clk_per_block": m["class_clk"], "half_rate_insts_per_block": m["half_rate_insts"],
+            "model_clk_per_block": m["model_clk"], "pipe_clk": m["pipe_clk"], "sgpr_readers": m["sgpr_readers"],
             "valu_insts_per_block": m["valu_insts"], "periods_per_block": m["periods_per_block"], "assumed_opcodes": m["assumed"],
             "weights_source": m["weights_source"] + " (tools/ubench_ops.hip, %d waves per SIMD; tools/valu_model.py)" % m["waves_per_simd_of_the_weights"]}
 
@@ -59,14 +60,35 @@ def mean_counter(directory, counter, kernel="paths_kernel"):
     return sum(vals) / len(vals), len(vals)
 
 
+def refresh_valu(out):
+    """Re-prices the loops of the entries that belong to the kernels as they compile now (no GPU needed: the ISA and
+    the committed issue-cost table): for a change of tools/valu_model.py or of the table, not of a kernel."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import isa_loop_count as I
+    table = json.load(open(out))
+    for key, rec in table.items():
+        mode = I.traffic_kernel_of(key)
+        ident = build_identity(mode)
+        if ident["isa_fingerprint"] != rec["isa_fingerprint"] or ident["source_sha256"] != rec["source_sha256"]:
+            raise SystemExit(f"{key}: the kernel changed since the PMC pass: profile again (tools/profile_r04.sh)")
+        rec["valu"] = valu_model_of(mode)
+    with open(out, "w") as fh:
+        json.dump(table, fh, indent=1, sort_keys=True)
+        fh.write("\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--key", required=True)
-    ap.add_argument("--write", required=True)
-    ap.add_argument("--fetch", required=True)
-    ap.add_argument("--source", required=True)
+    ap.add_argument("--key")
+    ap.add_argument("--write")
+    ap.add_argument("--fetch")
+    ap.add_argument("--source")
+    ap.add_argument("--refresh-valu", action="store_true")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     a = ap.parse_args()
+    if a.refresh_valu:
+        return refresh_valu(a.out)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import isa_loop_count as I
