@@ -240,6 +240,32 @@ def hbm_bound_kernels(eng, S, final, mode):
     b = 4.0 * nk * (p + 1)
     out["keepdata"] = {"bytes_per_launch": b, "kernel_ms": ms, "GBps": b / ms / 1e6, "frac_of_peak": b / ms / 1e6 / HBM_PEAK_GBS,
                        "n_paths": nk}
+    # a yardstick from the same box and the same minute (boxes differ by +- 5 % in what their HBM streams): ATen's own
+    # fill of the trajectory buffer and its sum over the final values -- the same bytes, nothing computed
+    try:
+        import torch
+
+        def torch_timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        eng.sync()
+        fill_ms = torch_timed(lambda: traj.fill_(1.0), 10)
+        sum_ms = torch_timed(lambda: final.sum(), 20)
+        out["box_yardstick"] = {"fill_GBps": b / fill_ms / 1e6, "fill_bytes": b, "sum_GBps": 4.0 * n / sum_ms / 1e6, "sum_bytes": 4.0 * n,
+                                "what": "torch.Tensor.fill_ over the keepdata buffer and torch.sum over the final values on this box, "
+                                        "torch events on torch's stream: a vendor kernel moving the same bytes, not a ceiling"}
+        out["keepdata"]["vs_box_fill"] = out["keepdata"]["GBps"] / out["box_yardstick"]["fill_GBps"]
+        out["values_stats"]["vs_box_sum"] = out["values_stats"]["GBps"] / out["box_yardstick"]["sum_GBps"]
+    except Exception as ex:  # a yardstick, never worth the line
+        out["box_yardstick"] = {"error": str(ex)}
     return out
 
 

@@ -99,6 +99,44 @@ __global__ __launch_bounds__(256) void pattern_d(float *out, unsigned long long 
   }
 }
 
+// E: the comb pattern with LINES consecutive 128-byte lines per stream per visit (a tile of 32 * LINES columns): does the
+// memory system prefer longer contiguous pieces per stream?  64 / (8 * LINES) streams per wave-wide 16-byte store.
+template <int LINES>
+__global__ __launch_bounds__(256) void pattern_e(float *out, unsigned long long n_rows, unsigned row_len) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr unsigned LPS = 8 * LINES;          // lanes per stream per store
+  constexpr unsigned SPI = 64 / LPS;           // streams per store instruction
+  const unsigned sub = lane / LPS, quad = lane % LPS;
+  const unsigned long long base_f = reinterpret_cast<uintptr_t>(out) >> 2;
+  const unsigned long long n_chunks = (n_rows / 2048) * 32;
+  for (unsigned long long c = (unsigned long long)blockIdx.x * 4 + wave; c < n_chunks; c += (unsigned long long)gridDim.x * 4) {
+    const unsigned long long row0 = (c / 32) * 2048 + (c % 32);
+    const unsigned phi = (unsigned)(base_f + row0 * row_len) & 31u;
+    const unsigned first_t = (phi != 0 && row0 != 0) ? 1u : 0u;
+    const unsigned n_t = (phi + row_len + 31) / 32;
+    for (unsigned t = first_t; t < n_t; t += LINES) {
+#pragma unroll
+      for (unsigned it = 0; it < 64 / SPI; ++it) {
+        const unsigned l = sub + SPI * it;
+        const long long a = (long long)((row0 + 32ull * l) * row_len) - phi + 32ll * t + 4 * quad;
+        if (t + quad / 8 < n_t && a >= 0 && (unsigned long long)a + 4 <= n_rows * row_len)
+          *reinterpret_cast<float4 *>(out + a) = make_float4(1.0f + t, 2.0f, 3.0f, 4.0f + l);
+      }
+    }
+  }
+}
+
+// F: a plain fill, 16 bytes per lane, a wave's store = 1 KiB contiguous, the grid strides over the array (ATen's shape)
+__global__ __launch_bounds__(256) void pattern_f(float4 *out, unsigned long long n4) {
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256)
+    out[i] = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
+}
+// G: the same, one workgroup per 4 KiB piece and no loop (a grid of n4 / 256 workgroups)
+__global__ __launch_bounds__(256) void pattern_g(float4 *out, unsigned long long n4) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) out[i] = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
+}
+
 int main(int argc, char **argv) {
   const unsigned long long n_rows = 4000000;
   const unsigned row_len = argc > 1 ? atoi(argv[1]) : 361;
@@ -139,6 +177,48 @@ int main(int argc, char **argv) {
              4.0 * (n_rows / 2048 * 2048) * row_len / ms / 1e6);
     }
   }
+  for (int lines : {1, 2, 4, 8}) {
+    for (int bpc : {4, 8}) {
+      float ms = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        if (lines == 1) hipLaunchKernelGGL(pattern_e<1>, dim3(256 * bpc), dim3(256), 0, 0, d, n_rows, row_len);
+        if (lines == 2) hipLaunchKernelGGL(pattern_e<2>, dim3(256 * bpc), dim3(256), 0, 0, d, n_rows, row_len);
+        if (lines == 4) hipLaunchKernelGGL(pattern_e<4>, dim3(256 * bpc), dim3(256), 0, 0, d, n_rows, row_len);
+        if (lines == 8) hipLaunchKernelGGL(pattern_e<8>, dim3(256 * bpc), dim3(256), 0, 0, d, n_rows, row_len);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      printf("row_len=%u bpc=%d E comb, %d lines per stream per visit: %.3f ms  %.0f GB/s\n", row_len, bpc, lines, ms,
+             4.0 * (n_rows / 2048 * 2048) * row_len / ms / 1e6);
+    }
+  }
+  {
+    const unsigned long long n4 = n_rows * row_len / 4;
+    for (int bpc : {4, 8, 16, 0}) {
+      float ms = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        if (bpc) hipLaunchKernelGGL(pattern_f, dim3(256 * bpc), dim3(256), 0, 0, reinterpret_cast<float4 *>(d), n4);
+        else hipLaunchKernelGGL(pattern_g, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<float4 *>(d), n4);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      printf("row_len=%u bpc=%d %s: %.3f ms  %.0f GB/s\n", row_len, bpc, bpc ? "F fill, 16 B per lane, grid stride" : "G fill, one 4 KiB piece per workgroup", ms, bytes / ms / 1e6);
+    }
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipEventRecord(e0));
+      CK(hipMemsetAsync(d, 0, n_rows * row_len * 4ull, 0));
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    printf("row_len=%u hipMemsetAsync: %.3f ms  %.0f GB/s\n", row_len, ms, bytes / ms / 1e6);
+  }
+  if (argc > 2) return 0;  // a second argument: skip the unaligned-piece sweeps
   for (int lds_kb : {8, 19, 39, 79}) {     // 160 KiB / lds -> 20(cap 8), 8, 4, 2 workgroups per CU
     for (int spin : {0, 2000, 8000}) {
       float ms = 0;
