@@ -33,7 +33,17 @@ def test_bench_line_carries_the_contract_fields():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.001  # HIP-event kernel time fits inside the step
     assert d["result"]["hist_total"] == 4000000
-    assert 0 < d["valu"]["frac"] < 1
+    v = d["valu"]
+    assert 0 < v["frac"] < 1
+    # round 4: the clock sampled by the launches themselves; the loop priced at class cost is a bound (<= 1), the
+    # same loop at the probes' measured costs rides beside it; the library says what it was built from
+    assert 1.2 < v["held_clock_ghz"] < 2.5
+    assert 0.5 < v["weighted_frac"] <= 1.0 and v["weighted_frac"] < v["weighted_frac_measured_costs"] < 1.12 * v["weighted_frac"]
+    assert v["weighted_model"]["class_clk_per_block"] == 2 * v["weighted_model"]["valu_insts_per_block"] + 2 * v["weighted_model"]["half_rate_insts_per_block"]
+    assert len(d["build_digest"]) == 64
+    y = d["hbm_bound_kernels"]["box_yardstick"]
+    assert 1000 < y["fill_GBps"] < 8000 and 20 < y["sum_GBps"] < 8000  # the sum is over this run's 4e6 values: microseconds
+    assert d["hbm_bound_kernels"]["keepdata"]["vs_box_fill"] == pytest.approx(d["hbm_bound_kernels"]["keepdata"]["GBps"] / y["fill_GBps"])
 
 
 def test_rccl_collectives_of_the_multi_rank_path_run_with_one_rank():

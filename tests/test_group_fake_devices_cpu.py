@@ -1,4 +1,4 @@
-"""smmc_group_* and the C++ drop-in's n_gpus calls with THREE distinct devices, on the CPU, under ThreadSanitizer
+"""smmc_group_* and the C++ drop-in's n_gpus calls with THREE and with EIGHT distinct devices, on the CPU, under ThreadSanitizer
 and AddressSanitizer + UBSan (the pool gives one GPU, so the per-device host threads, the
 once-only registration of the caller's buffer and the record merge had only ever run with one device or with one
 device listed several times).  The devices are tests/cpp/fake_hip.cpp's -- host memory behind the HIP runtime's
@@ -40,6 +40,14 @@ def _run(exe, **env):
 def test_three_device_group_and_dropin(built, exe):
     text = _run(exe)
     assert "group of 3 device(s)" in text and "shard 2 on device 2" in text
+
+
+def test_eight_device_group_and_dropin_under_tsan(built):
+    """The node the reference and BASELINE configs[3] / [4] are quoted on: eight devices -- eight host threads, eight
+    shards with a remainder, one registration of the caller's buffer, the merge of eight records; two groups over the
+    same eight devices at once."""
+    text = _run("group_fake_tsan", FAKE_HIP_DEVICES=8)
+    assert "group of 8 device(s)" in text and "shard 7 on device 7" in text
 
 
 @pytest.mark.parametrize("env", [dict(SMMC_PIN_HOST="chunk"), dict(SMMC_PIN_HOST="0"), dict(SMMC_HOST_CHUNK_PATHS=65536),
