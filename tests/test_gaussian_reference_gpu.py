@@ -57,6 +57,33 @@ def test_device_gaussian_stream_matches_the_reference_style_cpu_path(cpu_referen
           f"chi2 {fig['hist_chi2'][0]:.1f} / {fig['hist_chi2'][1]}")
 
 
+@pytest.mark.parametrize("n, periods, mean, std, hi", [
+    (300_000, 1000, 0.5, 0.83333, 1.0e6),   # BASELINE configs[4]'s shape: 1000 periods (final values around 1.5e5)
+    (500_000, 120, -0.2, 4.3, 5000.0),      # the spread of the historical table (4.3 % a month), a falling market
+])
+def test_other_shapes_and_parameters_match_the_reference_style_cpu_path(oracle, n, periods, mean, std, hi):
+    """The same two-sample comparison away from the headline's parameters: more periods (the draw's error, if it had
+    one, would accumulate over 1000 of them) and a standard deviation five times larger (the tails of the radius
+    table carry more of the result)."""
+    import stock_market_monte_carlo_amd as S
+    ref, _ = oracle.asref_gaussian_mc(n, periods, CAP, mean, std, 20260402)
+    ref_hist, _, _ = two_sample.product_histogram(ref, BINS, 0.0, hi)
+    eng = S.Engine(0)
+    try:
+        sim = S.Engine.make_sim(n, periods, S.MODE_GAUSSIAN, 0xC0FFEE, initial_capital=CAP, gauss_mean=mean, gauss_std=std,
+                                n_bins=BINS, hist_lo=0.0, hist_hi=hi)
+        r = eng.simulate(sim, want_final=True, want_stats=True)
+        st = eng.read_stats(r.stats_raw)
+        got = r.final.cpu().numpy()
+    finally:
+        eng.close()
+    h, under, over = two_sample.product_histogram(got, BINS, 0.0, hi)
+    assert np.array_equal(h, st.hist) and under == st.underflow and over == st.overflow and st.count == n
+    fig = two_sample.compare(got, ref, CAP, hist_a=st.hist, hist_b=ref_hist)
+    print(f"{n} x {periods}, N({mean}, {std}): log mean {fig['log_mean_se']:.2f} SE, log std {fig['log_std_se']:.2f} SE, "
+          f"KS {fig['ks_scaled']:.2f}, chi2 {fig['hist_chi2'][0]:.1f} / {fig['hist_chi2'][1]}")
+
+
 def test_dropin_gaussian_matches_the_reference_style_cpu_path(cpu_reference, tmp_path):
     """smmc::mc_simulations_gpu_gaussian through the C++ drop-in layer (tests/cpp/dropin_check.cpp dumps its
     result vector): the same comparison, and the values are those of the C ABI's stream v3 for that seed."""
