@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <thread>
 #include <vector>
 
@@ -68,6 +69,7 @@ static void expected_record(const smmc_sim &s, smmc_stats *st, std::vector<uint6
     st->below += v < s.below_threshold;
     st->min = std::fmin(st->min, v);
     st->max = std::fmax(st->max, v);
+    if (!s.n_bins) continue;  // no histogram asked for: no bucket, no underflow / overflow count (as the kernel)
     if (v < s.hist_lo) st->underflow += 1;
     else if (v < s.hist_hi) {
       int b = int((double(v) - s.hist_lo) * inv);
@@ -225,6 +227,77 @@ int main() {
     bool threw = false;
     try { mc_simulations_gpu(counter, 10, 36, 1000.f, table, totals, G + 1); } catch (const std::invalid_argument &) { threw = true; }
     EXPECT(threw);  // one shard more than there are devices
+  }
+  // 6. the RCCL merge with G distinct devices (FAKE_RCCL=1: tests/cpp/fake_rccl.cpp is the librccl.so.1 on the library
+  //    path -- host memory, completes inside ncclGroupEnd, refuses ranks that disagree).  What real RCCL would show as a
+  //    hang: a rank missing from the bracket, unequal counts; what it would show as garbage: a wrong offset or type.
+  if (std::getenv("FAKE_RCCL")) {
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    typedef long (*counter_fn)(void);
+    typedef void (*fail_fn)(long);
+    counter_fn collectives = lib ? reinterpret_cast<counter_fn>(dlsym(lib, "fake_rccl_collectives")) : nullptr;
+    counter_fn brackets = lib ? reinterpret_cast<counter_fn>(dlsym(lib, "fake_rccl_brackets")) : nullptr;
+    counter_fn live = lib ? reinterpret_cast<counter_fn>(dlsym(lib, "fake_rccl_live_comms")) : nullptr;
+    fail_fn fail_after = lib ? reinterpret_cast<fail_fn>(dlsym(lib, "fake_rccl_fail_after")) : nullptr;
+    EXPECT(collectives && brackets && live && fail_after);  // not the fake: the real librccl must never meet the fake runtime
+    if (collectives && brackets && live && fail_after) {
+      smmc_group *gr = nullptr, *gh = nullptr;
+      EXPECT(smmc_group_create(devices, G, SMMC_MERGE_RCCL, &gr) == SMMC_OK && live() == G);
+      EXPECT(smmc_group_create(devices, G, SMMC_MERGE_HOST, &gh) == SMMC_OK);
+      if (gr && gh) {
+        EXPECT(smmc_group_set_table(gr, table.data(), uint32_t(table.size())) == SMMC_OK);
+        EXPECT(smmc_group_set_table(gh, table.data(), uint32_t(table.size())) == SMMC_OK);
+        double engines_ms = -1, comm_ms = -1, merge_ms = -1;
+        EXPECT(smmc_group_timings(gr, &engines_ms, &comm_ms, &merge_ms) == SMMC_OK && comm_ms >= 0.0);
+        for (uint32_t bins : {64u, 0u, 1000u}) {
+          const uint64_t n = 2000003;
+          smmc_sim s = make_sim(SMMC_MODE_TABLE, 31 + bins, (1ull << 40) + 7, n, 360, bins);
+          smmc_stats sr, sh;
+          std::vector<uint64_t> hr(bins + 1, 77), hh(bins + 1, 77), want_hist;
+          const long c0 = collectives(), b0 = brackets();
+          const int rc = smmc_group_simulate(gr, &s, nullptr, nullptr, nullptr, nullptr, &sr, hr.data());
+          if (rc != SMMC_OK) std::printf("%s\n", smmc_last_error());
+          EXPECT(rc == SMMC_OK);
+          EXPECT(collectives() - c0 == (bins ? 2 : 1) && brackets() - b0 == 1);  // ONE bracket: the counters, the buckets
+          EXPECT(smmc_group_simulate(gh, &s, nullptr, nullptr, nullptr, nullptr, &sh, hh.data()) == SMMC_OK);
+          EXPECT(std::memcmp(&sr, &sh, sizeof sr) == 0 && hr == hh && hr[bins] == 77);  // the same bits as the host merge
+          smmc_stats want;
+          expected_record(s, &want, want_hist);
+          hr.resize(bins);
+          EXPECT(sr.count == n && sr.below == want.below && sr.underflow == want.underflow && sr.overflow == want.overflow);
+          EXPECT(sr.min == want.min && sr.max == want.max && hr == want_hist && sr.n_bins == bins);
+        }
+        // a collective that fails on the second device: an error with RCCL's words, nothing left queued, and the next call works
+        smmc_sim s = make_sim(SMMC_MODE_GAUSSIAN, 5, 0, 300001, 36, 16);
+        smmc_stats sr, sh;
+        std::vector<uint64_t> hr(16), hh(16);
+        fail_after(2);  // device 0's two all-reduces are posted, device 1's first one fails
+        EXPECT(smmc_group_simulate(gr, &s, nullptr, nullptr, nullptr, nullptr, &sr, hr.data()) == SMMC_ERR_HIP);
+        EXPECT(std::strstr(smmc_last_error(), "RCCL all-reduce") != nullptr && std::strstr(smmc_last_error(), "injected") != nullptr);
+        EXPECT(smmc_group_simulate(gr, &s, nullptr, nullptr, nullptr, nullptr, &sr, hr.data()) == SMMC_OK);
+        EXPECT(smmc_group_simulate(gh, &s, nullptr, nullptr, nullptr, nullptr, &sh, hh.data()) == SMMC_OK);
+        EXPECT(std::memcmp(&sr, &sh, sizeof sr) == 0 && hr == hh);
+      }
+      smmc_group_destroy(gr);
+      smmc_group_destroy(gh);
+      EXPECT(live() == 0);
+      // the same device twice is not a clique RCCL accepts: refused by smmc_group_create, with a reason
+      const int twice[2] = {0, 0};
+      smmc_group *bad = nullptr;
+      EXPECT(smmc_group_create(twice, 2, SMMC_MERGE_RCCL, &bad) != SMMC_OK && bad == nullptr);
+      // the C++ drop-in with SMMC_GROUP_MERGE=rccl: the summary of the n_gpus call, merged by the all-reduce
+      smmc::fix_seed(true, 4242);
+      const long n = 3000001;
+      smmc::Summary by_host = smmc::mc_summary(n, 360, 1000.f, false, table, 0.f, 0.f, 1000.f, 64, 0.f, 2500.f, G);
+      setenv("SMMC_GROUP_MERGE", "rccl", 1);
+      const long c0 = collectives();
+      smmc::Summary by_rccl = smmc::mc_summary(n, 360, 1000.f, false, table, 0.f, 0.f, 1000.f, 64, 0.f, 2500.f, G);
+      unsetenv("SMMC_GROUP_MERGE");
+      EXPECT(collectives() - c0 >= 2);
+      EXPECT(by_rccl.count == by_host.count && by_rccl.below == by_host.below && by_rccl.hist == by_host.hist);
+      EXPECT(by_rccl.min == by_host.min && by_rccl.max == by_host.max && by_rccl.sum == by_host.sum && by_rccl.sumsq == by_host.sumsq);
+      std::printf("rccl merge over %d fake devices: ok so far (%ld collectives)\n", G, collectives());
+    }
   }
   if (fake_hip_registered_ranges() != 0) { std::printf("FAIL: %zu host ranges still registered\n", fake_hip_registered_ranges()); ++fails; }
   std::printf(fails ? "group_fake_devices: %d failure(s)\n" : "group_fake_devices: ok\n", fails);

@@ -17,8 +17,8 @@ SAN = os.path.join(ROOT, "oracle", "_san")
 
 @pytest.fixture(scope="module")
 def built():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_san/group_fake_tsan", "_san/group_fake_asan"],
-                          stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_san/group_fake_tsan", "_san/group_fake_asan",
+                           "_san/fake_rccl_tsan/librccl.so.1", "_san/fake_rccl_asan/librccl.so.1"], stdout=subprocess.DEVNULL)
 
 
 def _run(exe, **env):
@@ -48,6 +48,24 @@ def test_eight_device_group_and_dropin_under_tsan(built):
     same eight devices at once."""
     text = _run("group_fake_tsan", FAKE_HIP_DEVICES=8)
     assert "group of 8 device(s)" in text and "shard 7 on device 7" in text
+
+
+@pytest.mark.parametrize("exe, devices", [("group_fake_tsan", 3), ("group_fake_asan", 3), ("group_fake_tsan", 8)])
+def test_rccl_merge_with_several_devices_over_a_fake_librccl(built, exe, devices):
+    """SMMC_MERGE_RCCL with G > 1 -- ncclCommInitAll over G devices, ONE ncclGroupStart / ncclGroupEnd bracket per call
+    with two all-reduces per device, the merged integers read back from device 0, doubles and min / max on the host --
+    had only ever run with G = 1 (the pool has one GPU).  tests/cpp/fake_rccl.cpp is the librccl.so.1 that
+    smmc_group.cpp's dlopen finds here: host memory, completes inside ncclGroupEnd, and REFUSES what real RCCL would
+    answer with a hang (a rank missing from the bracket, unequal numbers of collectives) or with garbage (ranks that
+    disagree on count / type / operation).  Checked: the merged record equals the host merge's bit for bit (64, 0 and
+    1000 buckets) and the definition's; one bracket and 2 (1 without buckets) collectives per call; a collective that
+    fails on the second device gives SMMC_ERR_HIP with RCCL's words and the next call works; every communicator is
+    destroyed; one device listed twice is refused; the C++ drop-in under SMMC_GROUP_MERGE=rccl.  It cannot show that
+    real RCCL over xGMI works -- only that what this library asks of it is well-formed for G ranks."""
+    san = "tsan" if exe.endswith("tsan") else "asan"
+    text = _run(exe, FAKE_RCCL=1, FAKE_HIP_DEVICES=devices,
+                LD_LIBRARY_PATH=os.path.join(SAN, f"fake_rccl_{san}") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    assert f"rccl merge over {devices} fake devices: ok so far" in text and "RCCL communicator in" in text
 
 
 @pytest.mark.parametrize("env", [dict(SMMC_PIN_HOST="chunk"), dict(SMMC_PIN_HOST="0"), dict(SMMC_HOST_CHUNK_PATHS=65536),
