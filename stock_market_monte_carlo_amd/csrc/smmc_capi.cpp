@@ -137,7 +137,12 @@ struct smmc_engine {
   float *d_select_out = nullptr;               // kMaxRanks
   void *d_scratch_stats = nullptr;             // one packed record with SMMC_MAX_BINS buckets
   unsigned long long *d_work_counter = nullptr;  // the comb keepdata kernel's chunk queue
-  unsigned long long *d_hist_spread = nullptr;   // values_stats: kHistSpread copies of the bucket array
+  // Bucket counts of the launch in flight: paths_kernel adds into copy 0, values_stats into kHistSpread copies;
+  // finalize_kernel folds them into the caller's record and zeroes them again, so the array is ZERO between
+  // launches and neither it nor the record is memset per call.  hist_dirty: an enqueue failed between the kernel
+  // and its finalize -- the next user clears the whole array first (hist_acc_ready).
+  unsigned long long *d_hist_spread = nullptr;
+  bool hist_dirty = false;
 
   // SMMC_FLAG_STREAM_REF (smmc_ref_kernels.hip)
   float *d_ref_final = nullptr;     // final values of a launch that asked for none (statistics are formed from them)
@@ -289,9 +294,22 @@ int timing_end(smmc_engine *e) {
 
 // One pass over n device floats -> packed statistics record (smmc_engine_values_stats after its argument
 // checks; also the statistics of a SMMC_FLAG_STREAM_REF launch).  Device must be current.
+// The engine's bucket accumulator, allocated and cleared on first use and cleared again after a failed enqueue.
+int hist_acc_ready(smmc_engine *e) {
+  const size_t bytes = sizeof(unsigned long long) * smmc::kHistSpread * SMMC_MAX_BINS;
+  if (!e->d_hist_spread) {
+    SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_hist_spread), bytes));
+    e->hist_dirty = true;
+  }
+  if (e->hist_dirty) {
+    SMMC_HIP(hipMemsetAsync(e->d_hist_spread, 0, bytes, e->stream));
+    e->hist_dirty = false;
+  }
+  return SMMC_OK;
+}
+
 int values_stats_enqueue(smmc_engine *e, const float *d_values, uint64_t n, float below_threshold, uint32_t n_bins,
                          float hist_lo, float hist_hi, void *d_stats, bool timed) {
-  SMMC_HIP(hipMemsetAsync(d_stats, 0, smmc_stats_bytes(n_bins), e->stream));
   smmc::ValuesArgs a;
   std::memset(&a, 0, sizeof a);
   a.values = d_values;
@@ -304,10 +322,9 @@ int values_stats_enqueue(smmc_engine *e, const float *d_values, uint64_t n, floa
   a.hist_inv = n_bins ? static_cast<double>(n_bins) / (static_cast<double>(hist_hi) - static_cast<double>(hist_lo)) : 0.0;
   a.partials = e->d_partials;
   a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
-  if (n_bins && n) {  // spread copies of the bucket array (see ValuesArgs)
-    if (!e->d_hist_spread)
-      SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_hist_spread), sizeof(unsigned long long) * smmc::kHistSpread * SMMC_MAX_BINS));
-    SMMC_HIP(hipMemsetAsync(e->d_hist_spread, 0, sizeof(unsigned long long) * smmc::kHistSpread * n_bins, e->stream));
+  if (n_bins) {  // spread copies of the bucket array (see ValuesArgs), zero now and zero again after finalize_kernel
+    const int rc = hist_acc_ready(e);
+    if (rc) return rc;
     a.hist_spread = e->d_hist_spread;
     a.spread = smmc::kHistSpread;
   }
@@ -321,6 +338,7 @@ int values_stats_enqueue(smmc_engine *e, const float *d_values, uint64_t n, floa
     if (v >= 1 && v <= 16) per_cu = static_cast<uint32_t>(v);
   }
   const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min(e->compute_units * per_cu, e->max_grid)));
+  e->hist_dirty = n_bins != 0;  // until the finalize that clears the accumulator is in the queue
   if (n) {
     int rc = timed ? timing_begin(e) : SMMC_OK;
     if (rc) return rc;
@@ -334,6 +352,7 @@ int values_stats_enqueue(smmc_engine *e, const float *d_values, uint64_t n, floa
   }
   SMMC_HIP(smmc::launch_finalize(e->d_partials, n ? grid : 0u, static_cast<smmc_stats *>(d_stats), n_bins, e->stream,
                                  a.hist_spread, a.spread));
+  e->hist_dirty = false;
   return SMMC_OK;
 }
 
@@ -446,7 +465,8 @@ int enqueue_ref_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, fl
   return SMMC_OK;
 }
 
-// Enqueue: (zero record) -> paths kernel -> finalize.  Device must be current.
+// Enqueue: paths kernel -> finalize (two launches: the record is written whole by finalize_kernel, the bucket
+// accumulator is left zero by it).  Device must be current.
 int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float *d_chunk_mean,
                        float *d_chunk_var, void *d_stats) {
   if (s->flags & SMMC_FLAG_STREAM_REF) return enqueue_ref_simulation(e, s, d_final, d_chunk_mean, d_chunk_var, d_stats);
@@ -456,10 +476,14 @@ int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float 
   a.d_chunk_var = d_chunk_var;
   const uint64_t n_chunks = (s->n_paths + smmc::kBlock - 1) / smmc::kBlock;
   const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(n_chunks, e->max_grid));
-  if (d_stats) {
-    SMMC_HIP(hipMemsetAsync(d_stats, 0, smmc_stats_bytes(s->n_bins), e->stream));
+  if (d_stats) {  // no memset: finalize_kernel writes the whole record and leaves the accumulator zero again
     a.partials = e->d_partials;
-    a.d_hist = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_stats) + sizeof(smmc_stats));
+    if (s->n_bins) {
+      const int rc = hist_acc_ready(e);
+      if (rc) return rc;
+      a.d_hist = e->d_hist_spread;  // copy 0
+      e->hist_dirty = true;
+    }
   }
   a.clock_probe = e->timing ? e->d_clock : nullptr;
   if (grid > 0) {
@@ -477,8 +501,11 @@ int enqueue_simulation(smmc_engine *e, const smmc_sim *s, float *d_final, float 
     rc = timing_end(e);
     if (rc) return rc;
   }
-  if (d_stats)
-    SMMC_HIP(smmc::launch_finalize(e->d_partials, grid, static_cast<smmc_stats *>(d_stats), s->n_bins, e->stream));
+  if (d_stats) {
+    SMMC_HIP(smmc::launch_finalize(e->d_partials, grid, static_cast<smmc_stats *>(d_stats), s->n_bins, e->stream,
+                                   s->n_bins ? e->d_hist_spread : nullptr, s->n_bins ? 1u : 0u));
+    e->hist_dirty = false;
+  }
   return SMMC_OK;
 }
 

@@ -124,9 +124,11 @@ struct ShardProgress {  // one per device and call: deltas go to the call's tota
   static void on_progress(void *self, int64_t finished) {
     ShardProgress *p = static_cast<ShardProgress *>(self);
     if (finished <= p->reported) return;
+    // the total is advanced UNDER the lock: two devices that finish a chunk at once must report in the order of their
+    // totals (found with eight fake devices: 7 then 5), and callers' callbacks are not asked to be re-entrant
+    std::lock_guard<std::mutex> lock(*p->report_lock);
     const int64_t now = p->total->fetch_add(finished - p->reported, std::memory_order_acq_rel) + (finished - p->reported);
     p->reported = finished;
-    std::lock_guard<std::mutex> lock(*p->report_lock);  // callers' callbacks are not asked to be re-entrant
     if (p->user_counter) {
       int64_t cur = __atomic_load_n(const_cast<int64_t *>(p->user_counter), __ATOMIC_RELAXED);
       if (now > cur) __atomic_store_n(const_cast<int64_t *>(p->user_counter), now, __ATOMIC_RELEASE);

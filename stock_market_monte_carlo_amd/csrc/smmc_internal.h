@@ -120,9 +120,10 @@ hipError_t launch_radix_pick(int pass, uint32_t n_ranks, SelectState *st, const 
 // `div`: SMMC_DIV_* of smmc.h (how a launch divides by 100: simulate_path in smmc_kernels.hip)
 hipError_t launch_paths(const KernelArgs &a, int div, uint32_t grid, size_t lds_bytes,
                         hipStream_t stream);
+// hist_acc: `spread` copies of n_bins bucket counts accumulated by the launch before; folded into the record and zeroed
+// again (the engine keeps the array zero between launches: smmc_capi.cpp, hist_acc_ready)
 hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, smmc_stats *d_stats,
-                           uint32_t n_bins, hipStream_t stream, const unsigned long long *hist_spread = nullptr,
-                           uint32_t spread = 0);
+                           uint32_t n_bins, hipStream_t stream, unsigned long long *hist_acc, uint32_t spread);
 hipError_t launch_keepdata(const KernelArgs &a, bool exact_div, int tile, int waves, uint32_t grid,
                            hipStream_t stream);
 // comb form of keepdata (rows [0, 2048 n_super) of a call; see keepdata_comb_kernel)

@@ -656,13 +656,21 @@ __global__ __launch_bounds__(kBlock) void paths_kernel(const KernelArgs k) {
 constexpr int kFinalizeBlock = 1024;
 __global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const BlockPartial *partials,
                                                                   uint32_t n_partials, smmc_stats *out,
-                                                                  uint32_t n_bins, const unsigned long long *hist_spread,
+                                                                  uint32_t n_bins, unsigned long long *hist_acc,
                                                                   uint32_t spread) {
-  if (spread) {  // fold the spread copies of the bucket array (values_stats) into the record's
+  // The bucket counts were accumulated in the engine's own array (one copy by paths_kernel, kHistSpread copies by
+  // values_stats): fold them into the record's and LEAVE THE ARRAY ZERO for the next launch -- the record needs no
+  // memset before a launch and the accumulator none after it (two launches per step instead of three).
+  if (spread) {
     unsigned long long *hist = reinterpret_cast<unsigned long long *>(out + 1);
     for (uint32_t b = threadIdx.x; b < n_bins; b += kFinalizeBlock) {
       unsigned long long c = 0;
-      for (uint32_t r = 0; r < spread; ++r) c += hist_spread[static_cast<size_t>(r) * n_bins + b];
+      for (uint32_t r = 0; r < spread; ++r) {
+        unsigned long long *src = hist_acc + static_cast<size_t>(r) * n_bins + b;
+        const unsigned long long v = *src;
+        c += v;
+        if (v) *src = 0;
+      }
       hist[b] = c;
     }
   }
@@ -1275,9 +1283,9 @@ hipError_t launch_paths(const KernelArgs &a, int div, uint32_t grid, size_t lds_
 }
 
 hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, smmc_stats *d_stats,
-                           uint32_t n_bins, hipStream_t stream, const unsigned long long *hist_spread, uint32_t spread) {
+                           uint32_t n_bins, hipStream_t stream, unsigned long long *hist_acc, uint32_t spread) {
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalizeBlock), 0, stream, partials, n_partials, d_stats,
-                     n_bins, hist_spread, spread);
+                     n_bins, hist_acc, spread);
   return hipGetLastError();
 }
 

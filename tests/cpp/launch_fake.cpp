@@ -71,7 +71,17 @@ hipError_t launch_paths(const KernelArgs &a, int, uint32_t grid, size_t, hipStre
 }
 
 hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, smmc_stats *out, uint32_t n_bins, hipStream_t,
-                           const unsigned long long *, uint32_t) {
+                           unsigned long long *hist_acc, uint32_t spread) {
+  // as finalize_kernel: the bucket counts were accumulated in the engine's own array; fold, and leave it zero
+  unsigned long long *hist = reinterpret_cast<unsigned long long *>(out + 1);
+  for (uint32_t b = 0; spread && b < n_bins; ++b) {
+    unsigned long long c = 0;
+    for (uint32_t r = 0; r < spread; ++r) {
+      c += hist_acc[static_cast<size_t>(r) * n_bins + b];
+      hist_acc[static_cast<size_t>(r) * n_bins + b] = 0;
+    }
+    hist[b] = c;
+  }
   out->count = out->below = out->underflow = out->overflow = 0;
   out->sum = out->sumsq = 0.0;
   out->min = std::numeric_limits<float>::infinity();

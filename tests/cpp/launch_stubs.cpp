@@ -10,7 +10,7 @@ hipError_t launch_radix_hist(const float *, uint64_t, int, uint32_t, const Selec
                              hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_radix_pick(int, uint32_t, SelectState *, const unsigned long long *, float *, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_paths(const KernelArgs &, int, uint32_t, size_t, hipStream_t) { return hipErrorNoDevice; }
-hipError_t launch_finalize(const BlockPartial *, uint32_t, smmc_stats *, uint32_t, hipStream_t, const unsigned long long *, uint32_t) { return hipErrorNoDevice; }
+hipError_t launch_finalize(const BlockPartial *, uint32_t, smmc_stats *, uint32_t, hipStream_t, unsigned long long *, uint32_t) { return hipErrorNoDevice; }
 hipError_t launch_keepdata(const KernelArgs &, bool, int, int, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_keepdata_comb(const KernelArgs &, bool, int, uint32_t, uint64_t, uint64_t, int, uint32_t, unsigned long long *,
                                 hipStream_t) { return hipErrorNoDevice; }

@@ -38,8 +38,13 @@ def test_bench_line_carries_the_contract_fields():
     # round 4: the clock sampled by the launches themselves; the loop priced at class cost is a bound (<= 1), the
     # same loop at the probes' measured costs rides beside it; the library says what it was built from
     assert 1.2 < v["held_clock_ghz"] < 2.5
-    assert 0.5 < v["weighted_frac"] <= 1.0 and v["weighted_frac"] < v["weighted_frac_measured_costs"] < 1.12 * v["weighted_frac"]
-    assert v["weighted_model"]["class_clk_per_block"] == 2 * v["weighted_model"]["valu_insts_per_block"] + 2 * v["weighted_model"]["half_rate_insts_per_block"]
+    if v["weighted_model"] is None:
+        # profiles/pmc_traffic.json belongs to other kernel sources than this build's: bench.py prices nothing with it
+        # (tests/test_measurement_cpu.py is the test that fails until the profile pass has been run again)
+        assert v["weighted_frac"] is None and v["weighted_frac_measured_costs"] is None
+    else:
+        assert 0.5 < v["weighted_frac"] <= 1.0 and v["weighted_frac"] < v["weighted_frac_measured_costs"] < 1.12 * v["weighted_frac"]
+        assert v["weighted_model"]["class_clk_per_block"] == 2 * v["weighted_model"]["valu_insts_per_block"] + 2 * v["weighted_model"]["half_rate_insts_per_block"]
     assert len(d["build_digest"]) == 64
     y = d["hbm_bound_kernels"]["box_yardstick"]
     assert 1000 < y["fill_GBps"] < 8000 and 20 < y["sum_GBps"] < 8000  # the sum is over this run's 4e6 values: microseconds

@@ -69,7 +69,11 @@ def test_rccl_merge_with_several_devices_over_a_fake_librccl(built, exe, devices
 
 
 @pytest.mark.parametrize("env", [dict(SMMC_PIN_HOST="chunk"), dict(SMMC_PIN_HOST="0"), dict(SMMC_HOST_CHUNK_PATHS=65536),
-                                 dict(SMMC_PIN_HOST="chunk", SMMC_HOST_CHUNK_PATHS=131072)])
+                                 dict(SMMC_PIN_HOST="chunk", SMMC_HOST_CHUNK_PATHS=131072),
+                                 # eight devices reporting 17 chunks each: the progress callback must see a total that
+                                 # never goes back (it did, 7 then 5, until the total was advanced under the lock)
+                                 dict(SMMC_HOST_CHUNK_PATHS=65536, FAKE_HIP_DEVICES=8)])
 def test_pinning_policies_and_chunk_lengths_with_three_devices(built, env):
-    """Every SMMC_PIN_HOST policy and short chunks (46 per shard): the same checks; under ThreadSanitizer."""
+    """Every SMMC_PIN_HOST policy and short chunks (46 per shard; 17 per shard on eight devices): the same checks; under
+    ThreadSanitizer."""
     _run("group_fake_tsan", **env)

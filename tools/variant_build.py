@@ -1,7 +1,7 @@
 """Development: builds an experimental VARIANT of the library from a patched scratch copy of csrc/ -- never from the
 product sources, never over the product library -- for interleaved A/B runs on one box (SMMC_LIB=<variant>).
 
-usage: variant_build.py TAG FILE 'OLD' 'NEW' [FILE 'OLD' 'NEW' ...]   ->  stock_market_monte_carlo_amd/_build/libsmmc_hip_TAG.so
+usage: [VARIANT_CSRC=dir] variant_build.py TAG [FILE 'OLD' 'NEW' ...]   ->  stock_market_monte_carlo_amd/_build/libsmmc_hip_TAG.so
 """
 import os
 import shutil
@@ -19,7 +19,7 @@ def main():
     assert len(edits) % 3 == 0
     tmp = tempfile.mkdtemp(prefix="smmc_variant_")
     csrc = os.path.join(tmp, "csrc")
-    shutil.copytree(B.CSRC, csrc)
+    shutil.copytree(os.environ.get("VARIANT_CSRC", B.CSRC), csrc)  # VARIANT_CSRC: e.g. csrc/ of an earlier commit (git worktree)
     for i in range(0, len(edits), 3):
         path = os.path.join(csrc, edits[i])
         text = open(path).read()
