@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: world_size-2 and -3 gloo groups exchange per-shard statistics
+"""The N > 1 path on CPU: world_size-2, -3 and -8 gloo groups exchange per-shard statistics
 records (built by the oracle for each rank's path range) through the product's
 gather-and-merge, and must reproduce the oracle's whole-run statistics."""
 import ctypes as C
@@ -49,11 +49,11 @@ def _worker(rank, world, port, n_total, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])  # 8 = the node BASELINE configs[3] / [4] are quoted on
 def test_gloo_gather_merge_matches_whole_run(world, tmp_path, oracle, table):
     from stock_market_monte_carlo_amd import _lib
     _lib.lib()
-    n_total = 10007  # not divisible by 2 or 3: the remainder must not be dropped
+    n_total = 10007  # not divisible by 2, 3 or 8: the remainder must not be dropped
     mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
     whole = oracle.counter_mc(oracle.make_params(oracle.MODE_GAUSSIAN, 24, n_total, 1234, table=table, n_bins=32,
                                                  hist_lo=0.0, hist_hi=3000.0))
