@@ -9,7 +9,7 @@ python -c "from stock_market_monte_carlo_amd import build; import sys; sys.exit(
 hipcc -O3 --offload-arch=gfx950 tools/ubench_store_pattern.hip -o /tmp/ubench_store_pattern || exit 1
 for round in 1 2; do
   timeout -k 10 120 /tmp/ubench_store_pattern 361 skip > $O/store_pattern_$round.txt 2>&1 || exit 1
-  grep "B contiguous\|D comb, 1 rows\|E comb\|fill\|Memset" $O/store_pattern_$round.txt
+  grep "B contiguous\|D comb, 1 rows\|E comb\|H comb\|fill\|Memset" $O/store_pattern_$round.txt
 done
 timeout -k 10 200 python tools/bench_keepdata.py > $O/bench_keepdata.jsonl 2>$O/bench_keepdata.err || exit 1
 python -c "

@@ -126,6 +126,30 @@ __global__ __launch_bounds__(256) void pattern_e(float *out, unsigned long long 
   }
 }
 
+// H: the comb pattern cut in TIME: one launch per tile column t, every wave stores ONE tile (one line of each of its 64
+// streams: 8 wave-wide stores) and ends -- what a trajectory kernel would look like if a wave handed its 64 running totals
+// on to the next launch instead of living for a whole row.  Round 4: do short-lived waves stream better here too?
+__global__ __launch_bounds__(256) void pattern_h(float *out, unsigned long long n_rows, unsigned row_len, unsigned t) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned sub = lane / 8, quad = lane % 8;
+  const unsigned long long base_f = reinterpret_cast<uintptr_t>(out) >> 2;
+  const unsigned long long n_chunks = (n_rows / 2048) * 32;
+  const unsigned long long c = (unsigned long long)blockIdx.x * 4 + wave;
+  if (c >= n_chunks) return;
+  const unsigned long long row0 = (c / 32) * 2048 + (c % 32);
+  const unsigned phi = (unsigned)(base_f + row0 * row_len) & 31u;
+  const unsigned first_t = (phi != 0 && row0 != 0) ? 1u : 0u;
+  const unsigned n_t = (phi + row_len + 31) / 32;
+  if (t < first_t || t >= n_t) return;
+#pragma unroll
+  for (unsigned it = 0; it < 8; ++it) {
+    const unsigned l = sub + 8 * it;
+    const long long a = (long long)((row0 + 32ull * l) * row_len) - phi + 32ll * t + 4 * quad;
+    if (a >= 0 && (unsigned long long)a + 4 <= n_rows * row_len)
+      *reinterpret_cast<float4 *>(out + a) = make_float4(1.0f + t, 2.0f, 3.0f, 4.0f + l);
+  }
+}
+
 // F: a plain fill, 16 bytes per lane, a wave's store = 1 KiB contiguous, the grid strides over the array (ATen's shape)
 __global__ __launch_bounds__(256) void pattern_f(float4 *out, unsigned long long n4) {
   for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256)
@@ -193,6 +217,21 @@ int main(int argc, char **argv) {
       printf("row_len=%u bpc=%d E comb, %d lines per stream per visit: %.3f ms  %.0f GB/s\n", row_len, bpc, lines, ms,
              4.0 * (n_rows / 2048 * 2048) * row_len / ms / 1e6);
     }
+  }
+  {
+    const unsigned long long n_chunks = (n_rows / 2048) * 32;
+    const unsigned n_t = (31 + row_len + 31) / 32;
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipEventRecord(e0));
+      for (unsigned t = 0; t < n_t; ++t)
+        hipLaunchKernelGGL(pattern_h, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, 0, d, n_rows, row_len, t);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    printf("row_len=%u H comb cut in time, %u launches of one-tile waves: %.3f ms  %.0f GB/s\n", row_len, n_t, ms,
+           4.0 * (n_rows / 2048 * 2048) * row_len / ms / 1e6);
   }
   {
     const unsigned long long n4 = n_rows * row_len / 4;
