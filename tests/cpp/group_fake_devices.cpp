@@ -19,6 +19,7 @@
 
 extern "C" float fake_path_value(uint64_t id, uint32_t key0, uint32_t key1, uint32_t n_periods, float capital);
 extern "C" void fake_hip_fail_mallocs_on(int device);
+extern "C" void fake_launch_fail_finalize(int n);
 extern "C" size_t fake_hip_live_allocations(void);
 extern "C" size_t fake_hip_registered_ranges(void);
 
@@ -228,6 +229,32 @@ int main() {
     try { mc_simulations_gpu(counter, 10, 36, 1000.f, table, totals, G + 1); } catch (const std::invalid_argument &) { threw = true; }
     EXPECT(threw);  // one shard more than there are devices
   }
+  // 5b. the bucket accumulator of an engine is zero between launches because finalize_kernel leaves it so (no memset per
+  //     call); an enqueue that fails between a kernel and its fold leaves counts behind, and the NEXT call must clear
+  //     them first: the record after the failure is the record of that call alone, not of one and a half
+  {
+    smmc_engine *e = nullptr;
+    EXPECT(smmc_engine_create(0, nullptr, &e) == SMMC_OK);
+    if (e) {
+      EXPECT(smmc_engine_set_table(e, table.data(), uint32_t(table.size())) == SMMC_OK);
+      const uint64_t n = 700001;
+      smmc_sim s = make_sim(SMMC_MODE_TABLE, 77, 5, n, 360, 64);
+      std::vector<float> out(n);
+      std::vector<uint64_t> hist(64), want_hist;
+      smmc_stats st, want;
+      expected_record(s, &want, want_hist);
+      EXPECT(smmc_engine_simulate_to_host(e, &s, out.data(), nullptr, nullptr, nullptr, &st, hist.data()) == SMMC_OK && hist == want_hist);
+      fake_launch_fail_finalize(1);
+      EXPECT(smmc_engine_simulate_to_host(e, &s, out.data(), nullptr, nullptr, nullptr, &st, hist.data()) != SMMC_OK);
+      fake_launch_fail_finalize(0);
+      std::fill(hist.begin(), hist.end(), 5);
+      EXPECT(smmc_engine_simulate_to_host(e, &s, out.data(), nullptr, nullptr, nullptr, &st, hist.data()) == SMMC_OK);
+      EXPECT(hist == want_hist && st.count == n && st.below == want.below);
+      EXPECT(smmc_engine_simulate_to_host(e, &s, out.data(), nullptr, nullptr, nullptr, &st, hist.data()) == SMMC_OK && hist == want_hist);
+      smmc_engine_destroy(e);
+    }
+  }
+
   // 6. the RCCL merge with G distinct devices (FAKE_RCCL=1: tests/cpp/fake_rccl.cpp is the librccl.so.1 on the library
   //    path -- host memory, completes inside ncclGroupEnd, refuses ranks that disagree).  What real RCCL would show as a
   //    hang: a rank missing from the bracket, unequal counts; what it would show as garbage: a wrong offset or type.

@@ -19,6 +19,10 @@ extern "C" float fake_path_value(uint64_t id, uint32_t key0, uint32_t key1, uint
   return capital * (0.5f + static_cast<float>(z & 0xFFFFu) / 65536.0f * 1.5f);
 }
 
+// test hook: the next n launch_finalize calls fail (an enqueue error between a kernel and its fold)
+static int g_fail_finalize = 0;
+extern "C" void fake_launch_fail_finalize(int n) { g_fail_finalize = n; }
+
 namespace smmc {
 
 hipError_t launch_paths(const KernelArgs &a, int, uint32_t grid, size_t, hipStream_t) {
@@ -72,6 +76,10 @@ hipError_t launch_paths(const KernelArgs &a, int, uint32_t grid, size_t, hipStre
 
 hipError_t launch_finalize(const BlockPartial *partials, uint32_t n_partials, smmc_stats *out, uint32_t n_bins, hipStream_t,
                            unsigned long long *hist_acc, uint32_t spread) {
+  if (g_fail_finalize > 0) {
+    --g_fail_finalize;
+    return hipErrorLaunchFailure;
+  }
   // as finalize_kernel: the bucket counts were accumulated in the engine's own array; fold, and leave it zero
   unsigned long long *hist = reinterpret_cast<unsigned long long *>(out + 1);
   for (uint32_t b = 0; spread && b < n_bins; ++b) {
