@@ -17,6 +17,9 @@
 //                        83-110 a full std::sort) without sorting or copying anything.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "smmc_internal.h"
 
 namespace smmc {
@@ -180,28 +183,69 @@ constexpr uint32_t kRadixCopies = 7;  // 7 x 2049 words = 56 KiB
 
 constexpr int kRadixBlock = 1024;  // 16 waves share one set of LDS histograms: 2 workgroups fill a CU
 
-// Pass 0: every value counts, by its top 11 key bits.  Passes 1 / 2: a value counts into
-// the histogram of the one group whose prefix it shares (if any), by its next 11 / last
-// 10 bits.  The group search is a select chain, so there is one (predicated) LDS atomic
-// per value whatever the number of groups.
+// Pass 0: every value counts, by its top 11 key bits.  Passes 1 / 2: a value counts into the histogram of the one
+// group whose prefix it shares (if any), by its next 11 / last 10 bits: one (predicated) LDS atomic per value whatever
+// the number of groups.
+//
+// Finding the group.  Round 2's select chain -- for each of the kMaxRanks possible groups a compare and a select, both
+// half rate -- cost 64 of the ~80 clocks a value took, and passes 1 / 2 ran at 82-87 us per 1e8 values where pass 0
+// (7 VALU per value) takes 67.  Now the 11 key bits that tell this pass's groups apart -- the top 11 in pass 1, the
+// middle 11 in pass 2 -- index a 2048-entry LDS table whose entry is (the group's whole prefix << 3 | group), or
+// all ones: one ds_read_b32, a shift and ONE compare say whether the value belongs to a group and to which.  Groups
+// have distinct prefixes by construction (radix_pick_kernel), so in pass 1 their table slots are distinct; in pass 2
+// two groups can share their middle 11 bits while differing above them (1.5 and 3.0 do): the workgroup that finds
+// such a collision while filling the table takes the select chain instead (kernel-uniform: every workgroup sees the
+// same groups).  Both forms count exactly the same values.
+constexpr uint32_t kNoGroup = 0xFFFFFFFFu;
+
 template <int kPass>
-__device__ __forceinline__ void radix_take(uint32_t key, uint32_t n_groups, const uint32_t *gprefix, uint32_t *lds_hist) {
-  if constexpr (kPass == 0) {
-    atomicAdd(&lds_hist[key >> 21], 1u);
-  } else {
-    constexpr uint32_t kShift = kPass == 1 ? 21u : 10u;
-    const uint32_t head = key >> kShift;
-    int32_t slot = -1;
+__device__ __forceinline__ void radix_take_chain(uint32_t key, uint32_t n_groups, const uint32_t *gprefix, uint32_t *lds_hist) {
+  constexpr uint32_t kShift = kPass == 1 ? 21u : 10u;
+  const uint32_t head = key >> kShift;
+  int32_t slot = -1;
 #pragma unroll
-    for (uint32_t g = 0; g < kMaxRanks; ++g)
-      slot = (g < n_groups && head == gprefix[g]) ? static_cast<int32_t>(g * kRadixBins) : slot;
-    if (slot >= 0) atomicAdd(&lds_hist[slot + (kPass == 1 ? ((key >> 10) & 2047u) : (key & 1023u))], 1u);
-  }
+  for (uint32_t g = 0; g < kMaxRanks; ++g)
+    slot = (g < n_groups && head == gprefix[g]) ? static_cast<int32_t>(g * kRadixBins) : slot;
+  if (slot >= 0) atomicAdd(&lds_hist[slot + (kPass == 1 ? ((key >> 10) & 2047u) : (key & 1023u))], 1u);
 }
 
 template <int kPass>
+__device__ __forceinline__ void radix_take_table(uint32_t key, const uint32_t *lds_tab, uint32_t *lds_hist) {
+  constexpr uint32_t kShift = kPass == 1 ? 21u : 10u;
+  const uint32_t head = key >> kShift;                          // 11 or 22 bits
+  const uint32_t e = lds_tab[kPass == 1 ? head : (head & 2047u)];
+  if ((e >> 3) == head)                                         // kNoGroup >> 3 is no 22-bit head
+    atomicAdd(&lds_hist[(e & 7u) * kRadixBins + (kPass == 1 ? ((key >> 10) & 2047u) : (key & 1023u))], 1u);
+}
+static_assert(kMaxRanks <= 8, "a table entry keeps the group in three bits");
+
+template <int kPass, typename Take>
+__device__ __forceinline__ void radix_stream(const float *values, uint64_t n, Take &&take_one) {
+  const uint32_t tid = threadIdx.x;
+  const uint64_t gtid = static_cast<uint64_t>(blockIdx.x) * kRadixBlock + tid;
+  const uint64_t gsize = static_cast<uint64_t>(gridDim.x) * kRadixBlock;
+  const uint64_t mis = (reinterpret_cast<uintptr_t>(values) >> 2) & 3u;
+  uint64_t head = mis ? 4 - mis : 0;
+  if (head > n) head = n;
+  if (gtid < head) take_one(order_key(values[gtid]));
+  const float4 *body = reinterpret_cast<const float4 *>(values + head);
+  const uint64_t n4 = (n - head) >> 2;
+  stream_float4(body, n4, gtid, gsize, [&](const float4 &v) {
+    take_one(order_key(v.x));
+    take_one(order_key(v.y));
+    take_one(order_key(v.z));
+    take_one(order_key(v.w));
+  });
+  const uint64_t tail0 = head + (n4 << 2);
+  if (tail0 + gtid < n) take_one(order_key(values[tail0 + gtid]));
+}
+
+// LDS: pass 0 kRadixCopies histograms; passes 1 / 2 one histogram per possible group (n_ranks: the group count lives on
+// the device), then the 2048-entry group table and one flag word.
+template <int kPass>
 __global__ __launch_bounds__(kRadixBlock) void radix_hist_kernel(const float *values, uint64_t n,
-                                                                 const SelectState *st, unsigned long long *g_hist) {
+                                                                 const SelectState *st, unsigned long long *g_hist,
+                                                                 uint32_t n_ranks, uint32_t force_chain) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t *lds_all = reinterpret_cast<uint32_t *>(lds_raw);
   const uint32_t n_groups = kPass == 0 ? 1u : st->n_groups;
@@ -211,27 +255,32 @@ __global__ __launch_bounds__(kRadixBlock) void radix_hist_kernel(const float *va
   const uint32_t words = kPass == 0 ? kRadixCopies * hist_stride(kRadixBins) : n_groups * kRadixBins;
   uint32_t *lds_hist = kPass == 0 ? lds_all + (tid % kRadixCopies) * hist_stride(kRadixBins) : lds_all;
   for (uint32_t i = tid; i < words; i += kRadixBlock) lds_all[i] = 0u;
-  uint32_t gprefix[kMaxRanks];  // wave-uniform: scalar registers
+  if constexpr (kPass == 0) {
+    __syncthreads();
+    radix_stream<0>(values, n, [&](uint32_t key) { atomicAdd(&lds_hist[key >> 21], 1u); });
+  } else {
+    constexpr uint32_t kShift = kPass == 1 ? 21u : 10u;
+    uint32_t *lds_tab = lds_all + n_ranks * kRadixBins, *lds_flag = lds_tab + kRadixBins;
+    for (uint32_t i = tid; i < kRadixBins; i += kRadixBlock) lds_tab[i] = kNoGroup;
+    uint32_t gprefix[kMaxRanks];  // wave-uniform: scalar registers
 #pragma unroll
-  for (uint32_t g = 0; g < kMaxRanks; ++g) gprefix[g] = st->group_prefix[g] >> (kPass == 1 ? 21u : 10u);
-  __syncthreads();
-
-  const uint64_t gtid = static_cast<uint64_t>(blockIdx.x) * kRadixBlock + tid;
-  const uint64_t gsize = static_cast<uint64_t>(gridDim.x) * kRadixBlock;
-  const uint64_t mis = (reinterpret_cast<uintptr_t>(values) >> 2) & 3u;
-  uint64_t head = mis ? 4 - mis : 0;
-  if (head > n) head = n;
-  if (gtid < head) radix_take<kPass>(order_key(values[gtid]), n_groups, gprefix, lds_hist);
-  const float4 *body = reinterpret_cast<const float4 *>(values + head);
-  const uint64_t n4 = (n - head) >> 2;
-  stream_float4(body, n4, gtid, gsize, [&](const float4 &v) {
-    radix_take<kPass>(order_key(v.x), n_groups, gprefix, lds_hist);
-    radix_take<kPass>(order_key(v.y), n_groups, gprefix, lds_hist);
-    radix_take<kPass>(order_key(v.z), n_groups, gprefix, lds_hist);
-    radix_take<kPass>(order_key(v.w), n_groups, gprefix, lds_hist);
-  });
-  const uint64_t tail0 = head + (n4 << 2);
-  if (tail0 + gtid < n) radix_take<kPass>(order_key(values[tail0 + gtid]), n_groups, gprefix, lds_hist);
+    for (uint32_t g = 0; g < kMaxRanks; ++g) gprefix[g] = st->group_prefix[g] >> kShift;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t collide = force_chain;
+      for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t head = st->group_prefix[g] >> kShift, slot = kPass == 1 ? head : (head & 2047u);
+        if (lds_tab[slot] != kNoGroup) collide = 1u;
+        lds_tab[slot] = (head << 3) | g;
+      }
+      *lds_flag = collide;
+    }
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(*lds_flag))  // the same for every workgroup of the launch
+      radix_stream<kPass>(values, n, [&](uint32_t key) { radix_take_chain<kPass>(key, n_groups, gprefix, lds_hist); });
+    else
+      radix_stream<kPass>(values, n, [&](uint32_t key) { radix_take_table<kPass>(key, lds_tab, lds_hist); });
+  }
   __syncthreads();
   for (uint32_t b = tid; b < n_groups * kRadixBins; b += kRadixBlock) {
     uint32_t c = 0;
@@ -313,15 +362,26 @@ hipError_t launch_values_stats(const ValuesArgs &a, uint32_t grid, hipStream_t s
 
 hipError_t launch_radix_hist(const float *values, uint64_t n, int pass, uint32_t n_ranks, const SelectState *st,
                              unsigned long long *g_hist, uint32_t grid, hipStream_t stream) {
-  // sized for the worst case of one group per rank (the group count lives on the device)
+  // sized for the worst case of one group per rank (the group count lives on the device); passes 1 / 2: + the group
+  // table and its flag word
   const size_t lds = pass == 0 ? static_cast<size_t>(kRadixCopies) * (kRadixBins | 1u) * 4u
-                               : static_cast<size_t>(n_ranks) * kRadixBins * 4u;
+                               : (static_cast<size_t>(n_ranks) * kRadixBins + kRadixBins + 4u) * 4u;
+  // SMMC_RADIX_MATCH=chain: the select chain of round 2 for every value (A/B runs and tests)
+  static const uint32_t force_chain = [] {
+    const char *env = std::getenv("SMMC_RADIX_MATCH");
+    return (env && !std::strcmp(env, "chain")) ? 1u : 0u;
+  }();
+  if (lds > 60u * 1024u) {  // more than the default limit of dynamic LDS: opt in (160 KiB per CU on CDNA4; two of these workgroups fit)
+    const void *fn = pass == 1 ? reinterpret_cast<const void *>(radix_hist_kernel<1>) : reinterpret_cast<const void *>(radix_hist_kernel<2>);
+    const hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (err != hipSuccess) return err;
+  }
   if (pass == 0)
-    hipLaunchKernelGGL(radix_hist_kernel<0>, dim3(grid), dim3(kRadixBlock), lds, stream, values, n, st, g_hist);
+    hipLaunchKernelGGL(radix_hist_kernel<0>, dim3(grid), dim3(kRadixBlock), lds, stream, values, n, st, g_hist, n_ranks, force_chain);
   else if (pass == 1)
-    hipLaunchKernelGGL(radix_hist_kernel<1>, dim3(grid), dim3(kRadixBlock), lds, stream, values, n, st, g_hist);
+    hipLaunchKernelGGL(radix_hist_kernel<1>, dim3(grid), dim3(kRadixBlock), lds, stream, values, n, st, g_hist, n_ranks, force_chain);
   else
-    hipLaunchKernelGGL(radix_hist_kernel<2>, dim3(grid), dim3(kRadixBlock), lds, stream, values, n, st, g_hist);
+    hipLaunchKernelGGL(radix_hist_kernel<2>, dim3(grid), dim3(kRadixBlock), lds, stream, values, n, st, g_hist, n_ranks, force_chain);
   return hipGetLastError();
 }
 

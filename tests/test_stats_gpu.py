@@ -47,6 +47,55 @@ def test_order_statistics_bit_exact(eng, oracle, name, values):
         assert np.array_equal(eng.quartiles(_dev(eng, values)), oracle.quartiles(values))
 
 
+def _octave_twins():
+    """Two clusters an octave apart whose mantissas are equal down to bit 10: the ranks in the lower and in the upper
+    cluster share the MIDDLE 11 bits of their keys and differ in the top 11 -- the one case in which pass 2's group
+    table (keyed by the middle bits) cannot tell its groups apart and the kernel takes the select chain."""
+    rng = np.random.default_rng(17)
+    low_bits = rng.integers(0, 1024, 30001).astype(np.uint32)        # bits 0..9 vary, bits 10..22 are 1.5's
+    a = (np.float32(1.5).view(np.uint32) | low_bits).view(np.float32)
+    b = (np.float32(3.0).view(np.uint32) | low_bits[::-1]).view(np.float32)
+    return np.concatenate([a, b, -a[:5000], np.float32(6.0) + np.zeros(3000, dtype=np.float32)])
+
+
+@pytest.mark.parametrize("match", ["table", "chain"])
+def test_order_statistics_group_match_forms_agree(oracle, table, match):
+    """Round 4: passes 1 / 2 find a value's group through a 2048-entry LDS table instead of a select chain; a collision
+    of two groups in the table (octave twins) falls back to the chain inside the kernel, and SMMC_RADIX_MATCH=chain
+    forces the chain for every launch.  Every form, on every data set of this file and on the twins: the oracle's
+    sort, bit for bit.  (The environment variable is read once per process: a child process per form.)"""
+    import subprocess, sys, os, json
+    code = r"""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import stock_market_monte_carlo_amd as S
+from oracle import oracle as O
+import test_stats_gpu as T
+e = S.Engine(0)
+bad = []
+cases = list(T._cases()) + [("octave_twins", T._octave_twins())]
+for name, values in cases:
+    n = values.size
+    ranks = sorted({0, n - 1, n // 2, n // 4, min(n // 4 + n // 2, n - 1), min(7, n - 1), n * 9 // 10, max(n - 2, 0)})[:8]
+    got = e.order_statistics(torch.from_numpy(values).to("cuda:0"), ranks)
+    want = O.order_statistics(values, ranks)
+    same = np.array_equal(got, want) if name == "specials" else np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if not same: bad.append(name)
+    if n >= 4 and not np.array_equal(e.quartiles(torch.from_numpy(values).to("cuda:0")), O.quartiles(values)): bad.append(name + " quartiles")
+print(json.dumps({"bad": bad, "cases": len(cases)}))
+"""
+    env = dict(os.environ)
+    env.pop("SMMC_RADIX_MATCH", None)
+    if match == "chain":
+        env["SMMC_RADIX_MATCH"] = "chain"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["bad"] == [] and out["cases"] == 9, out
+
+
 def test_order_statistics_unaligned_views_and_ragged_sizes(eng, oracle):
     rng = np.random.default_rng(9)
     base = rng.normal(5000, 2000, 10007).astype(np.float32)
