@@ -348,7 +348,12 @@ __global__ __launch_bounds__(64 * kMaxRanks) void radix_pick_kernel(int pass, ui
 uint32_t values_hist_copies(uint32_t n_bins) {
   if (!n_bins) return 1;
   const uint32_t fit = (32u * 1024u / 4u) / (n_bins | 1u);  // keep the histogram within 32 KiB
-  return fit >= 16 ? 16u : fit >= 1 ? fit : 1u;
+  uint32_t most = 16;
+  if (const char *env = std::getenv("SMMC_STATS_HIST_COPIES")) {  // tuning knob: 1 ... 64
+    const long v = std::strtol(env, nullptr, 10);
+    if (v >= 1 && v <= 64) most = static_cast<uint32_t>(v);
+  }
+  return fit >= most ? most : fit >= 1 ? fit : 1u;
 }
 
 hipError_t launch_values_stats(const ValuesArgs &a, uint32_t grid, hipStream_t stream) {
