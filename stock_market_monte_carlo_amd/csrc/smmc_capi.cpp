@@ -137,7 +137,10 @@ struct smmc_engine {
 
   // order statistics workspace
   smmc::SelectState *d_select = nullptr;
-  unsigned long long *d_radix_hist = nullptr;  // kMaxRanks x 2048
+  unsigned long long *d_radix_hist = nullptr;  // kMaxRanks x 2048; zero between passes and calls (radix_pick_kernel
+                                               // clears what a pass counted); radix_dirty: an enqueue failed in between
+  bool radix_dirty = false;
+  smmc::SelectState *h_select = nullptr;       // page-locked: the call's ranks go up from here without a sync
   float *d_select_out = nullptr;               // kMaxRanks
   void *d_scratch_stats = nullptr;             // one packed record with SMMC_MAX_BINS buckets
   unsigned long long *d_work_counter = nullptr;  // the comb keepdata kernel's chunk queue
@@ -701,6 +704,7 @@ void smmc_engine_destroy(smmc_engine *e) {
   if (e->d_bm_tables) (void)hipFree(e->d_bm_tables);
   if (e->d_select) (void)hipFree(e->d_select);
   if (e->d_radix_hist) (void)hipFree(e->d_radix_hist);
+  if (e->h_select) (void)hipHostFree(e->h_select);
   if (e->d_select_out) (void)hipFree(e->d_select_out);
   if (e->d_scratch_stats) (void)hipFree(e->d_scratch_stats);
   if (e->d_work_counter) (void)hipFree(e->d_work_counter);
@@ -1302,13 +1306,21 @@ int smmc_engine_order_statistics(smmc_engine *e, const float *d_values, uint64_t
   if (!guard.ok) return fail(SMMC_ERR_HIP, "hipSetDevice(%d) failed", e->device);
   const size_t hist_bytes = sizeof(unsigned long long) * smmc::kMaxRanks * 2048;
   if (!e->d_select) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_select), sizeof(smmc::SelectState)));
-  if (!e->d_radix_hist) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_radix_hist), hist_bytes));
+  if (!e->d_radix_hist) {
+    SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_radix_hist), hist_bytes));
+    e->radix_dirty = true;
+  }
   if (!e->d_select_out) SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_select_out), sizeof(float) * smmc::kMaxRanks));
-  smmc::SelectState st;
-  std::memset(&st, 0, sizeof st);
-  for (uint32_t q = 0; q < n_ranks; ++q) st.rank[q] = ranks[q];
-  SMMC_HIP(hipMemcpyAsync(e->d_select, &st, sizeof st, hipMemcpyHostToDevice, e->stream));
-  SMMC_HIP(hipStreamSynchronize(e->stream));  // `st` is a local
+  if (!e->h_select) SMMC_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->h_select), sizeof(smmc::SelectState), hipHostMallocDefault));
+  if (e->radix_dirty) {
+    SMMC_HIP(hipMemsetAsync(e->d_radix_hist, 0, hist_bytes, e->stream));
+    e->radix_dirty = false;
+  }
+  // the state goes up from the engine's page-locked copy: every call ends with a synchronisation of the stream, so the
+  // copy of the call before has long been read
+  std::memset(e->h_select, 0, sizeof(smmc::SelectState));
+  for (uint32_t q = 0; q < n_ranks; ++q) e->h_select->rank[q] = ranks[q];
+  SMMC_HIP(hipMemcpyAsync(e->d_select, e->h_select, sizeof(smmc::SelectState), hipMemcpyHostToDevice, e->stream));
   // 1024-thread workgroups, four per CU of which two are resident (the LDS histograms allow no more);
   // the queued ones even out the CUs: 1e9 values 0.730 -> 0.699 ms per pass (2 -> 4 per CU)
   const uint64_t want = (n / 8 + 1023) / 1024;
@@ -1318,8 +1330,8 @@ int smmc_engine_order_statistics(smmc_engine *e, const float *d_values, uint64_t
     if (v >= 1 && v <= 16) radix_per_cu = static_cast<uint32_t>(v);
   }
   const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(want, 1), e->compute_units * radix_per_cu));
+  e->radix_dirty = true;  // until the last pick of the call is in the queue: an error return in between leaves counts behind
   for (int pass = 0; pass < 3; ++pass) {
-    SMMC_HIP(hipMemsetAsync(e->d_radix_hist, 0, hist_bytes, e->stream));
     int rc = timing_begin(e);
     if (rc) return rc;
     SMMC_HIP_TIMED(e, smmc::launch_radix_hist(d_values, n, pass, n_ranks, e->d_select, e->d_radix_hist, grid, e->stream));
@@ -1327,6 +1339,7 @@ int smmc_engine_order_statistics(smmc_engine *e, const float *d_values, uint64_t
     if (rc) return rc;
     SMMC_HIP(smmc::launch_radix_pick(pass, n_ranks, e->d_select, e->d_radix_hist, e->d_select_out, e->stream));
   }
+  e->radix_dirty = false;
   SMMC_HIP(hipMemcpyAsync(host_out, e->d_select_out, sizeof(float) * n_ranks, hipMemcpyDeviceToHost, e->stream));
   SMMC_HIP(hipStreamSynchronize(e->stream));
   return SMMC_OK;

@@ -113,7 +113,8 @@ struct SelectState {
 hipError_t launch_values_stats(const ValuesArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t launch_radix_hist(const float *values, uint64_t n, int pass, uint32_t n_ranks, const SelectState *st,
                              unsigned long long *g_hist, uint32_t grid, hipStream_t stream);
-hipError_t launch_radix_pick(int pass, uint32_t n_ranks, SelectState *st, const unsigned long long *g_hist,
+// also zeroes the part of g_hist the pass counted into (the array is zero between passes and calls)
+hipError_t launch_radix_pick(int pass, uint32_t n_ranks, SelectState *st, unsigned long long *g_hist,
                              float *d_out, hipStream_t stream);
 
 // Launch wrappers (defined in smmc_kernels.hip).  All asynchronous on `stream`.

@@ -211,6 +211,15 @@ hipError_t hipHostMalloc(void **ptr, size_t size, unsigned int) {
   *ptr = p;
   return hipSuccess;
 }
+hipError_t hipHostFree(void *ptr) {
+  if (!ptr) return hipSuccess;
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (!g_registered.erase(reinterpret_cast<uintptr_t>(ptr))) return done(hipErrorInvalidValue);
+  }
+  std::free(ptr);
+  return hipSuccess;
+}
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t *attributes, const void *ptr) {
   std::memset(attributes, 0, sizeof *attributes);
   const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);

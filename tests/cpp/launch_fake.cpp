@@ -113,7 +113,7 @@ size_t bm_tables_bytes(int stream) { return stream == 2 ? (1056 * 4 + 256 * 2) *
 hipError_t launch_values_stats(const ValuesArgs &, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_radix_hist(const float *, uint64_t, int, uint32_t, const SelectState *, unsigned long long *, uint32_t,
                              hipStream_t) { return hipErrorNoDevice; }
-hipError_t launch_radix_pick(int, uint32_t, SelectState *, const unsigned long long *, float *, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_radix_pick(int, uint32_t, SelectState *, unsigned long long *, float *, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_keepdata(const KernelArgs &, bool, int, int, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_keepdata_comb(const KernelArgs &, bool, int, uint32_t, uint64_t, uint64_t, int, uint32_t, unsigned long long *,
                                 hipStream_t) { return hipErrorNoDevice; }

@@ -8,7 +8,7 @@ namespace smmc {
 hipError_t launch_values_stats(const ValuesArgs &, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_radix_hist(const float *, uint64_t, int, uint32_t, const SelectState *, unsigned long long *, uint32_t,
                              hipStream_t) { return hipErrorNoDevice; }
-hipError_t launch_radix_pick(int, uint32_t, SelectState *, const unsigned long long *, float *, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_radix_pick(int, uint32_t, SelectState *, unsigned long long *, float *, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_paths(const KernelArgs &, int, uint32_t, size_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_finalize(const BlockPartial *, uint32_t, smmc_stats *, uint32_t, hipStream_t, unsigned long long *, uint32_t) { return hipErrorNoDevice; }
 hipError_t launch_keepdata(const KernelArgs &, bool, int, int, uint32_t, hipStream_t) { return hipErrorNoDevice; }
