@@ -233,18 +233,6 @@ def hbm_bound_kernels(eng, S, final, mode):
     ms = timed(lambda: eng.quartiles(final), 5)  # 3 histogram passes per call, each timed
     out["quartiles_radix_pass"] = {"bytes_per_launch": 4.0 * n, "kernel_ms": ms, "GBps": 4.0 * n / ms / 1e6,
                                    "frac_of_peak": 4.0 * n / ms / 1e6 / HBM_PEAK_GBS}
-    # the whole call as a caller sees it (update_quartiles, examples/visualize_returns_cpu_v2.cpp:83-111): the ranks go up,
-    # three passes and their picks run, five values come back; and the same on 1e6 values, where the launches ARE the call
-    t0 = time.perf_counter()
-    for _ in range(10):
-        eng.quartiles(final)
-    out["quartiles_radix_pass"]["call_ms"] = (time.perf_counter() - t0) / 10 * 1e3
-    small = final[:1_000_000]
-    eng.quartiles(small)
-    t0 = time.perf_counter()
-    for _ in range(50):
-        eng.quartiles(small)
-    out["quartiles_radix_pass"]["call_ms_1e6_values"] = (time.perf_counter() - t0) / 50 * 1e3
     nk, p = 4_000_000, N_PERIODS
     sim = S.Engine.make_sim(nk, p, mode, SEED)
     traj, _ = eng.simulate_keepdata(sim, want_final=False)
@@ -278,6 +266,19 @@ def hbm_bound_kernels(eng, S, final, mode):
         out["values_stats"]["vs_box_sum"] = out["values_stats"]["GBps"] / out["box_yardstick"]["sum_GBps"]
     except Exception as ex:  # a yardstick, never worth the line
         out["box_yardstick"] = {"error": str(ex)}
+    # LAST (these loops leave the device half idle, and the clocks of the measurements after them would show it):
+    # the whole quartiles call as a caller sees it (update_quartiles, examples/visualize_returns_cpu_v2.cpp:83-111): the ranks go up,
+    # three passes and their picks run, five values come back; and the same on 1e6 values, where the launches ARE the call
+    t0 = time.perf_counter()
+    for _ in range(10):
+        eng.quartiles(final)
+    out["quartiles_radix_pass"]["call_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+    small = final[:1_000_000]
+    eng.quartiles(small)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        eng.quartiles(small)
+    out["quartiles_radix_pass"]["call_ms_1e6_values"] = (time.perf_counter() - t0) / 50 * 1e3
     return out
 
 

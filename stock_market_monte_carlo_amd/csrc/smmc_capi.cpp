@@ -106,10 +106,6 @@ struct smmc_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t copy_stream = nullptr;  // lazily created, simulate_to_host only
-  // keepdata: the < 2048 rows the comb kernel does not take run as a small tile-kernel launch of their own -- a
-  // workgroup or two for 50-150 us of one wave's latency -- on this stream, BESIDE the comb kernel instead of after it
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t compute_units = 0;
   uint32_t max_grid = 0;
   uint32_t keepdata_blocks_per_cu = 0;  // 0: as many keepdata workgroups as are resident
@@ -685,12 +681,6 @@ void smmc_engine_destroy(smmc_engine *e) {
     (void)hipStreamSynchronize(e->copy_stream);
     (void)hipStreamDestroy(e->copy_stream);
   }
-  if (e->aux_stream) {
-    (void)hipStreamSynchronize(e->aux_stream);
-    (void)hipStreamDestroy(e->aux_stream);
-  }
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->ev_order) (void)hipEventDestroy(e->ev_order);
   for (int i = 0; i < 2; ++i) {
@@ -849,16 +839,6 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
   }
   if (comb && !e->d_work_counter)
     SMMC_HIP(hipMalloc(reinterpret_cast<void **>(&e->d_work_counter), sizeof(unsigned long long)));
-  // Both kernels in one call: the rest rows go to the side of the comb kernel (SMMC_KEEPDATA_REST=serial: after it, as
-  // before round 4).  The two write disjoint rows, except the line in which the comb part ends: the same values twice.
-  bool rest_beside = comb && n_comb < sim->n_paths;
-  if (const char *env = std::getenv("SMMC_KEEPDATA_REST"))
-    if (!std::strcmp(env, "serial")) rest_beside = false;
-  if (rest_beside) {
-    if (!e->aux_stream) SMMC_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
-    if (!e->ev_fork) SMMC_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-    if (!e->ev_join) SMMC_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-  }
   rc = timing_begin(e);
   if (rc) return rc;
   // from here on a failure closes the timing pair before it returns
@@ -866,25 +846,6 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     (void)timing_end(e);
     return fail(SMMC_ERR_HIP, "%s failed: %s", what, hipGetErrorString(err));
   };
-  auto launch_rest = [&](hipStream_t on) {
-    smmc_sim rest = *sim;
-    rest.first_path = sim->first_path + n_comb;
-    rest.n_paths = sim->n_paths - n_comb;
-    smmc::KernelArgs a = make_args(e, &rest);
-    a.d_traj = d_traj + n_comb * row_len;
-    a.d_final = (d_final && !comb) ? d_final : nullptr;
-    return smmc::launch_keepdata(a, exact_div, tile, tile_waves, tile_grid, on);
-  };
-  if (rest_beside) {  // fork: after everything queued on the engine's stream so far, first in line for a CU
-    hipError_t err = hipEventRecord(e->ev_fork, e->stream);
-    if (err == hipSuccess) err = hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0);
-    if (err == hipSuccess) err = launch_rest(e->aux_stream);
-    if (err == hipSuccess) err = hipEventRecord(e->ev_join, e->aux_stream);
-    if (err != hipSuccess) {
-      (void)hipStreamSynchronize(e->aux_stream);
-      return bail(err, "launch_keepdata (beside the comb kernel)");
-    }
-  }
   if (comb) {
     smmc::KernelArgs a = make_args(e, sim);
     a.d_traj = d_traj;
@@ -903,10 +864,8 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     }
     const uint64_t n_wave_chunks = n_super * (32u / k_rows);
     const uint32_t per_cu = e->keepdata_blocks_per_cu ? e->keepdata_blocks_per_cu : 1u;
-    // one workgroup per CU takes all of a CU's LDS: with rest rows running beside, one CU is left to them (1 / 256 of the
-    // comb kernel's rate against 50-150 us of a tile-kernel wave's latency at the end of every call)
-    const uint64_t cus_for_comb = (rest_beside && e->compute_units > 1) ? e->compute_units - 1u : e->compute_units;
-    const uint32_t cgrid = static_cast<uint32_t>(std::min<uint64_t>((n_wave_chunks + waves - 1) / waves, cus_for_comb * per_cu));
+    const uint32_t cgrid = static_cast<uint32_t>(
+        std::min<uint64_t>((n_wave_chunks + waves - 1) / waves, static_cast<uint64_t>(e->compute_units) * per_cu));
     // Philox blocks drawn together per step (instruction-level parallelism at < 4 waves per SIMD)
     int per_step = (sim->n_periods / draws) % 2u == 0u ? 2 : 1;
     if (const char *env = std::getenv("SMMC_KEEPDATA_COMB_ILP")) {  // tuning knob
@@ -914,19 +873,16 @@ int smmc_engine_simulate_keepdata(smmc_engine *e, const smmc_sim *sim, float *d_
     }
     const hipError_t err = smmc::launch_keepdata_comb(a, exact_div, per_step, k_rows, n_wave_chunks, sim->n_paths, waves, cgrid,
                                                       e->d_work_counter, e->stream);
-    if (err != hipSuccess) {
-      if (rest_beside) (void)hipStreamSynchronize(e->aux_stream);  // nothing of this call may outlive its error return
-      return bail(err, "launch_keepdata_comb");
-    }
+    if (err != hipSuccess) return bail(err, "launch_keepdata_comb");
   }
-  if (rest_beside) {  // join: what follows on the engine's stream (the final-value gather, the caller's reads) sees both
-    const hipError_t err = hipStreamWaitEvent(e->stream, e->ev_join, 0);
-    if (err != hipSuccess) {
-      (void)hipStreamSynchronize(e->aux_stream);
-      return bail(err, "hipStreamWaitEvent");
-    }
-  } else if (n_comb < sim->n_paths) {
-    const hipError_t err = launch_rest(e->stream);
+  if (n_comb < sim->n_paths) {
+    smmc_sim rest = *sim;
+    rest.first_path = sim->first_path + n_comb;
+    rest.n_paths = sim->n_paths - n_comb;
+    smmc::KernelArgs a = make_args(e, &rest);
+    a.d_traj = d_traj + n_comb * row_len;
+    a.d_final = (d_final && !comb) ? d_final : nullptr;
+    const hipError_t err = smmc::launch_keepdata(a, exact_div, tile, tile_waves, tile_grid, e->stream);
     if (err != hipSuccess) return bail(err, "launch_keepdata");
   }
   if (comb && d_final) {  // the comb form leaves the final values to a gather of the last column

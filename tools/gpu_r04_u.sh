@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Record of an experiment: SMMC_KEEPDATA_REST existed only in the build these runs measured; the form was not kept -- DESIGN.md section 5.)
 # Round 4, GPU pass U: keepdata with the rest rows beside the comb kernel (product) against after it (SMMC_KEEPDATA_REST=serial),
 # interleaved; before that the keepdata test files.
 set -o pipefail
