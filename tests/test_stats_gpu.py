@@ -96,6 +96,35 @@ print(json.dumps({"bad": bad, "cases": len(cases)}))
     assert out["bad"] == [] and out["cases"] == 9, out
 
 
+def test_order_statistics_fuzz(eng, oracle):
+    """Seeded random data sets and rank sets against the oracle's sort: sizes 1 ... 3e5, normal / log-normal / few distinct
+    values / clusters an octave apart with shared mantissas (the group table's collision case) / signed mixtures, 1 ... 8
+    ranks with repeats -- the number of groups per pass, their prefixes and the table-or-chain decision all vary."""
+    rng = np.random.default_rng(20260406)
+    for case in range(60):
+        n = int(rng.choice([1, 2, 5, 63, 64, 65, 1000, 4097, 50001, 300007]))
+        kind = case % 5
+        if kind == 0:
+            v = rng.normal(0, 10.0 ** rng.integers(-3, 6), n)
+        elif kind == 1:
+            v = np.exp(rng.normal(8.7, rng.uniform(0.01, 1.0), n))
+        elif kind == 2:
+            v = rng.choice(rng.normal(0, 100, 5), n)
+        elif kind == 3:  # octave clusters: equal mantissa bits 10..22, different exponents
+            mant = np.uint32(rng.integers(0, 1 << 13)) << np.uint32(10)
+            exps = rng.integers(100, 150, 6).astype(np.uint32)
+            bits = (rng.choice(exps, n).astype(np.uint32) << np.uint32(23)) | mant | rng.integers(0, 1024, n).astype(np.uint32)
+            v = bits.view(np.float32)
+        else:
+            v = np.concatenate([rng.normal(-5, 1, n // 2), rng.normal(5e4, 3e3, n - n // 2)])
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        k = int(rng.integers(1, 9))
+        ranks = [int(r) for r in rng.integers(0, n, k)]
+        got = eng.order_statistics(_dev(eng, v), ranks)
+        want = oracle.order_statistics(v, ranks)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (case, n, kind, ranks)
+
+
 def test_order_statistics_unaligned_views_and_ragged_sizes(eng, oracle):
     rng = np.random.default_rng(9)
     base = rng.normal(5000, 2000, 10007).astype(np.float32)
