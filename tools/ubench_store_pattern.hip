@@ -150,6 +150,33 @@ __global__ __launch_bounds__(256) void pattern_h(float *out, unsigned long long 
   }
 }
 
+// I: the comb pattern in HALF lines: a visit writes 64 aligned bytes of each stream (4 lanes x 16 B, 16 streams per store), the
+// other half of the line comes with the same wave's next visit -- what a tile of 16 columns (half the LDS, twice the waves)
+// would store.  Every line is still written whole and by one wave, but in two pieces some microseconds apart.
+__global__ __launch_bounds__(256) void pattern_i(float *out, unsigned long long n_rows, unsigned row_len, int spin) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned sub = lane / 4, quad = lane % 4;
+  const unsigned long long base_f = reinterpret_cast<uintptr_t>(out) >> 2;
+  const unsigned long long n_chunks = (n_rows / 2048) * 32;
+  float acc = 1.0f + lane;
+  for (unsigned long long c = (unsigned long long)blockIdx.x * 4 + wave; c < n_chunks; c += (unsigned long long)gridDim.x * 4) {
+    const unsigned long long row0 = (c / 32) * 2048 + (c % 32);
+    const unsigned phi = (unsigned)(base_f + row0 * row_len) & 31u;
+    const unsigned first_h = (phi != 0 && row0 != 0) ? 2u : 0u;      // halves: skip the whole partial first line
+    const unsigned n_h = 2u * ((phi + row_len + 31) / 32);
+    for (unsigned h = first_h; h < n_h; ++h) {
+      for (int i = 0; i < spin; ++i) acc = __builtin_fmaf(acc, 1.0000001f, 0.5f);  // the compute between two visits
+#pragma unroll
+      for (unsigned it = 0; it < 4; ++it) {
+        const unsigned l = sub + 16 * it;
+        const long long a = (long long)((row0 + 32ull * l) * row_len) - phi + 16ll * h + 4 * quad;
+        if (a >= 0 && (unsigned long long)a + 4 <= n_rows * row_len)
+          *reinterpret_cast<float4 *>(out + a) = make_float4(acc, 2.0f, 3.0f, 4.0f + l);
+      }
+    }
+  }
+}
+
 // F: a plain fill, 16 bytes per lane, a wave's store = 1 KiB contiguous, the grid strides over the array (ATen's shape)
 __global__ __launch_bounds__(256) void pattern_f(float4 *out, unsigned long long n4) {
   for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256)
@@ -215,6 +242,20 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
       }
       printf("row_len=%u bpc=%d E comb, %d lines per stream per visit: %.3f ms  %.0f GB/s\n", row_len, bpc, lines, ms,
+             4.0 * (n_rows / 2048 * 2048) * row_len / ms / 1e6);
+    }
+  }
+  for (int bpc : {4, 8}) {
+    for (int spin : {0, 100, 400}) {
+      float ms = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(pattern_i, dim3(256 * bpc), dim3(256), 0, 0, d, n_rows, row_len, spin);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      printf("row_len=%u bpc=%d I comb in half lines, %d fma between visits: %.3f ms  %.0f GB/s\n", row_len, bpc, spin, ms,
              4.0 * (n_rows / 2048 * 2048) * row_len / ms / 1e6);
     }
   }
