@@ -145,3 +145,28 @@ def test_engine_R_equals_the_reference_loop_written_with_the_real_libstdcxx_clas
     la, lr = np.log(a.astype(np.float64) / 1000.0), np.log(r.astype(np.float64) / 1000.0)
     se = lr.std() / np.sqrt(lr.size) * np.sqrt(2.0)
     assert abs(la.mean() - lr.mean()) < 5 * se and abs(la.std() / lr.std() - 1.0) < 0.05
+
+
+import pytest
+
+
+@pytest.mark.parametrize("stream", [2, 3])
+def test_oracle_reproduces_the_frozen_counter_stream_vectors(oracle, table, stream):
+    """tests/golden/counter_stream_v{2,3}.json were frozen from the oracle when the stream contracts were fixed (round 2 /
+    round 3); the GPU suite compares the kernels with them, and the kernels with the oracle as it is built now.  This
+    is the third side, on the CPU: the oracle AS BUILT NOW against the frozen vectors -- so that a change that moves the
+    oracle and the kernels together (they share the generated Box-Muller tables, tools/gen_bm_tables.py) cannot pass
+    unnoticed where there is no GPU."""
+    with open(os.path.join(HERE, "golden", f"counter_stream_v{stream}.json")) as f:
+        gold = json.load(f)
+    modes = {"table": oracle.MODE_TABLE, "gaussian": oracle.MODE_GAUSSIAN}
+    assert gold["stream"] == stream and len(gold["cases"]) == 24
+    for c in gold["cases"]:
+        p = oracle.make_params(modes[c["mode"]], c["n_periods"], c["n_paths"], seed=c["seed"], first_path=c["first_path"],
+                               table=table, n_bins=c["n_bins"], hist_lo=c["hist_lo"], hist_hi=c["hist_hi"], stream=stream)
+        r = oracle.counter_mc(p)
+        st = r["stats"]
+        assert [int(x) for x in r["final"].view(np.uint32)] == c["final_bits"], (c["mode"], c["n_periods"], c["first_path"])
+        assert [int(x) for x in r["hist"]] == c["hist"]
+        assert (int(st.below), int(st.underflow), int(st.overflow)) == (c["below"], c["underflow"], c["overflow"])
+        assert st.sum == c["sum"] and st.sumsq == c["sumsq"] and float(st.min) == c["min"] and float(st.max) == c["max"]
