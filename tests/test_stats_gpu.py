@@ -157,6 +157,36 @@ def test_values_stats_matches_fused_simulation_statistics(eng, oracle, table):
     assert np.array_equal(q, oracle.quartiles(r.final.cpu().numpy()))
 
 
+def test_bucket_accumulator_is_clean_between_calls_of_every_shape(eng, oracle, table):
+    """Round 4: neither the record nor the engine's bucket accumulator is memset per call -- finalize_kernel folds the
+    accumulator into the record and zeroes what it read.  One engine, calls of changing shape back to back: fused
+    statistics of a simulation (one copy of the buckets), values_stats (sixteen), bucket counts from 0 to SMMC_MAX_BINS,
+    empty inputs, and quartiles in between (its own self-cleaning histogram): every record equals the oracle's, i.e.
+    nothing of an earlier call is left in a later one."""
+    from stock_market_monte_carlo_amd import Engine, MODE_TABLE, MODE_GAUSSIAN
+    rng = np.random.default_rng(5)
+    values = np.exp(rng.normal(8.7, 0.4, 70001)).astype(np.float32)
+    dv = _dev(eng, values)
+    for i, bins in enumerate([100, 16, 1000, 7, 4096, 0, 100, 1, 4096, 3]):
+        lo, hi = 0.0, float([20000.0, 9000.0, 30000.0][i % 3])
+        st = eng.read_stats(eng.values_stats(dv, below_threshold=6000.0, n_bins=bins, hist_lo=lo, hist_hi=hi))
+        ost, oh = oracle.values_stats(values, 6000.0, bins, lo, hi)
+        assert (st.count, st.below, st.underflow, st.overflow) == (ost.count, ost.below, ost.underflow, ost.overflow), bins
+        assert np.array_equal(st.hist, oh), bins
+        mode = MODE_TABLE if i % 2 else MODE_GAUSSIAN
+        sim = Engine.make_sim(20011 + 257 * i, 36, mode, 40 + i, n_bins=bins, hist_lo=lo, hist_hi=hi)
+        r = eng.simulate(sim, want_stats=True)
+        fused = eng.read_stats(r.stats_raw)
+        fin = r.final.cpu().numpy()
+        ost, oh = oracle.values_stats(fin, 1000.0, bins, lo, hi)
+        assert (fused.count, fused.below, fused.underflow, fused.overflow) == (ost.count, ost.below, ost.underflow, ost.overflow), bins
+        assert np.array_equal(fused.hist, oh), bins
+        if i % 3 == 0:
+            assert np.array_equal(eng.quartiles(r.final), oracle.quartiles(fin))
+        empty = eng.read_stats(eng.values_stats(dv[:0], below_threshold=1.0, n_bins=bins, hist_lo=lo, hist_hi=hi))
+        assert empty.count == 0 and int(np.asarray(empty.hist).sum()) == 0
+
+
 def test_reference_named_helpers(oracle):
     """update_quartiles / update_mean_std / update_count_below_min / reduce_mean_gpu."""
     import stock_market_monte_carlo_amd as S
