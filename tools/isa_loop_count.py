@@ -24,13 +24,32 @@ VARIANTS = {"gaussian": ("ILi1ELi0ELb0E", 4), "table": ("ILi0ELi0ELb1E", 8),
 
 
 def emit_asm(out_path, source="smmc_kernels.hip"):
-    """Device assembly of a kernel TU with exactly the product's compiler flags."""
+    """Device assembly of a kernel TU with exactly the product's compiler flags.  Kept beside the library's objects
+    under the same content key (source + headers + flags + compiler: build._object_key), so that a second caller --
+    the tests after a build, the driver's run after the builder's -- copies it instead of compiling for a minute."""
+    import shutil
     sys.path.insert(0, ROOT)
     from stock_market_monte_carlo_amd import build as B
+    cache = None
+    try:
+        cache = os.path.join(B.PKG, "_build", "asm", f"{source}.{B._object_key(os.path.join(B.CSRC, source))}.s")
+        if os.path.exists(cache) and os.path.getsize(cache) > 0:
+            shutil.copyfile(cache, out_path)
+            return out_path
+    except Exception:
+        cache = None
     cmd = [B.hipcc()] + [f for f in B.FLAGS if f != "-fPIC"] + [
         "-x", "hip", "-S", "--cuda-device-only", "-Wno-unused-command-line-argument",
         "-I" + os.path.join(ROOT, "include"), "-I" + B.CSRC, "-o", out_path, os.path.join(B.CSRC, source)]
     subprocess.check_call(cmd)
+    if cache:
+        try:
+            os.makedirs(os.path.dirname(cache), exist_ok=True)
+            tmp = f"{cache}.{os.getpid()}.tmp"
+            shutil.copyfile(out_path, tmp)
+            os.replace(tmp, cache)
+        except OSError:
+            pass
     return out_path
 
 
